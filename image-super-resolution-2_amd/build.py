@@ -1,0 +1,51 @@
+"""Build libff_hip.so (gfx950) in-tree with hipcc.  `python -m isr2_amd.build` or build()."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libff_hip.so")
+SOURCES = ["ff_runtime.hip", "conv_gemm.hip", "attention.hip", "norm_pool.hip", "dwconv.hip", "elementwise.hip",
+           "resample.hip", "freq.hip", "fusion_ops.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def cc(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        if verbose and r.stderr:
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(cc, SOURCES))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

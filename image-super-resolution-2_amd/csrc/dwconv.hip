@@ -1,0 +1,93 @@
+// Depth-wise convolutions on NHWC tensors (HBM-bound: one read of the tile + halo, one write):
+//   3x3 (+BN+GELU)  dat_arch.py:403-407,109 ; nafnet_arch.py:78-81
+//   5x5, 1x21, 21x1 large_kernel_attention.py:59-78 (LKA chain)
+//   Gaussian 5x5    edge_enhancement.py:62
+// Channels are the fastest axis, so a wave reads 64 consecutive channels (or 16 float4) of one tap
+// coalesced; the kh*kw taps of neighbouring pixels are served from L1/L2.  Weights are stored
+// tap-major [kh*kw][C] so the per-tap weight vector is also one coalesced load.
+//   out = act( (sum_taps w*x + bias) * post_scale + post_shift )
+#include "ff_common.h"
+
+struct DwParams {
+  const float* in; float* out; const float* w; const float* bias; const float* ps; const float* pt;
+  int ldi, ldo, B, H, W, C, Ho, Wo, KH, KW, sy, sx, py, px, act;
+};
+
+__global__ __launch_bounds__(256) void dwconv_vec4_kernel(DwParams p) {
+  const int c4n = p.C >> 2;
+  const long long total = (long long)p.B * p.Ho * p.Wo * c4n;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % c4n) * 4;
+    long long pix = idx / c4n;
+    const int ox = (int)(pix % p.Wo); pix /= p.Wo;
+    const int oy = (int)(pix % p.Ho);
+    const int b = (int)(pix / p.Ho);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < p.KH; ++ky) {
+      const int iy = oy * p.sy - p.py + ky;
+      if ((unsigned)iy >= (unsigned)p.H) continue;
+      for (int kx = 0; kx < p.KW; ++kx) {
+        const int ix = ox * p.sx - p.px + kx;
+        if ((unsigned)ix >= (unsigned)p.W) continue;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p.in + ((long long)(b * p.H + iy) * p.W + ix) * p.ldi + c);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + (long long)(ky * p.KW + kx) * p.C + c);
+        acc += x * w;
+      }
+    }
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = acc[e] + (p.bias ? p.bias[c + e] : 0.f);
+      if (p.ps) v = v * p.ps[c + e] + p.pt[c + e];
+      r[e] = ff_act(v, p.act);
+    }
+    *reinterpret_cast<f32x4*>(p.out + ((long long)(b * p.Ho + oy) * p.Wo + ox) * p.ldo + c) = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv_scalar_kernel(DwParams p) {
+  const long long total = (long long)p.B * p.Ho * p.Wo * p.C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % p.C);
+    long long pix = idx / p.C;
+    const int ox = (int)(pix % p.Wo); pix /= p.Wo;
+    const int oy = (int)(pix % p.Ho);
+    const int b = (int)(pix / p.Ho);
+    float acc = 0.f;
+    for (int ky = 0; ky < p.KH; ++ky) {
+      const int iy = oy * p.sy - p.py + ky;
+      if ((unsigned)iy >= (unsigned)p.H) continue;
+      for (int kx = 0; kx < p.KW; ++kx) {
+        const int ix = ox * p.sx - p.px + kx;
+        if ((unsigned)ix >= (unsigned)p.W) continue;
+        acc += p.in[((long long)(b * p.H + iy) * p.W + ix) * p.ldi + c] * p.w[(long long)(ky * p.KW + kx) * p.C + c];
+      }
+    }
+    float v = acc + (p.bias ? p.bias[c] : 0.f);
+    if (p.ps) v = v * p.ps[c] + p.pt[c];
+    p.out[((long long)(b * p.Ho + oy) * p.Wo + ox) * p.ldo + c] = ff_act(v, p.act);
+  }
+}
+
+extern "C" int ff_dwconv2d(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int Ho, int Wo,
+                           const float* w_tapmajor, const float* bias, int KH, int KW, int sy, int sx, int py, int px,
+                           const float* post_scale, const float* post_shift, int act, void* stream) {
+  FF_CHECK_ARG(in && out && w_tapmajor, "ff_dwconv2d: null pointer");
+  FF_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && ldi >= C && ldo >= C, "ff_dwconv2d: bad dims");
+  FF_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "ff_dwconv2d: post scale/shift must come together");
+  DwParams p;
+  p.in = in; p.out = out; p.w = w_tapmajor; p.bias = bias; p.ps = post_scale; p.pt = post_shift;
+  p.ldi = ldi; p.ldo = ldo; p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo;
+  p.KH = KH; p.KW = KW; p.sy = sy; p.sx = sx; p.py = py; p.px = px; p.act = act;
+  const bool v4 = (C % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)in & 15) == 0) &&
+                  (((uintptr_t)out & 15) == 0) && (((uintptr_t)w_tapmajor & 15) == 0);
+  const long long total = (long long)B * Ho * Wo * (v4 ? C / 4 : C);
+  long long nb = (total + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  if (v4)
+    hipLaunchKernelGGL(dwconv_vec4_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(dwconv_scalar_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+  FF_LAUNCH_CHECK("ff_dwconv2d");
+  return FF_OK;
+}

@@ -1,0 +1,157 @@
+// Bandwidth-bound pointwise kernels on [rows][C] (NHWC / token) tensors with row strides, so
+// channel slices of wider tensors are addressed in place (no chunk / cat copies).
+//   ff_mix2   out = ka*a*ca[c]*pa[p] + kb*b*cb[c]*pb[p]      (optionally clamped to [0,1])
+//             hat_arch.py:306 (x + attn + conv*scale), dat_arch.py:551-556,655-660 (AIM),
+//             nafnet_arch.py:121 (x * sca, applied to the conv3 weight columns), hierarchical gates ...
+//   ff_fma3   out = a + alpha*b*c                           SimpleGate / SGFN gate / LKA x + s*(t*attn)
+//   ff_affine out = act(x*scale[c] + shift[c])              eval-mode BatchNorm in front of zero-padded convs
+//   layout    NCHW image <-> NHWC working tensors, mean shift, reflect/zero padding, crop, clamp
+#include "ff_common.h"
+
+__global__ __launch_bounds__(256) void mix2_kernel(float* __restrict__ out, int ldo, const float* __restrict__ a, int lda,
+                                                   const float* __restrict__ b, int ldb, long long rows, int C, float ka,
+                                                   float kb, const float* __restrict__ ca, const float* __restrict__ cb,
+                                                   const float* __restrict__ pa, int ldpa, const float* __restrict__ pb,
+                                                   int ldpb, int clamp01) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    float v = ka * a[r * lda + c];
+    if (ca) v *= ca[c];
+    if (pa) v *= pa[r * ldpa];
+    if (b) {
+      float u = kb * b[r * ldb + c];
+      if (cb) u *= cb[c];
+      if (pb) u *= pb[r * ldpb];
+      v += u;
+    }
+    if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+    out[r * ldo + c] = v;
+  }
+}
+
+extern "C" int ff_mix2(float* out, int ldo, const float* a, int lda, const float* b, int ldb, long long rows, int C,
+                       float ka, float kb, const float* ca, const float* cb, const float* pa, int ldpa,
+                       const float* pb, int ldpb, int clamp01, void* stream) {
+  FF_CHECK_ARG(out && a && rows > 0 && C > 0 && ldo >= C && lda >= C && (!b || ldb >= C), "ff_mix2: bad args");
+  long long nb = (rows * C + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(mix2_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, rows, C,
+                     ka, kb, ca, cb, pa, ldpa, pb, ldpb, clamp01);
+  FF_LAUNCH_CHECK("ff_mix2");
+  return FF_OK;
+}
+
+__global__ __launch_bounds__(256) void fma3_kernel(float* __restrict__ out, int ldo, const float* __restrict__ a, int lda,
+                                                   const float* __restrict__ b, int ldb, const float* __restrict__ c_,
+                                                   int ldc, long long rows, int C, float alpha) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    float v = alpha * b[r * ldb + c] * c_[r * ldc + c];
+    if (a) v += a[r * lda + c];
+    out[r * ldo + c] = v;
+  }
+}
+
+extern "C" int ff_fma3(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c, int ldc,
+                       long long rows, int C, float alpha, void* stream) {
+  FF_CHECK_ARG(out && b && c && rows > 0 && C > 0 && ldo >= C && ldb >= C && ldc >= C && (!a || lda >= C), "ff_fma3: bad args");
+  long long nb = (rows * C + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(fma3_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, out, ldo, a, lda, b, ldb, c, ldc,
+                     rows, C, alpha);
+  FF_LAUNCH_CHECK("ff_fma3");
+  return FF_OK;
+}
+
+__global__ __launch_bounds__(256) void affine_kernel(float* __restrict__ out, int ldo, const float* __restrict__ in, int ldi,
+                                                     long long rows, int C, const float* __restrict__ sc,
+                                                     const float* __restrict__ sh, int act) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    out[r * ldo + c] = ff_act(in[r * ldi + c] * sc[c] + sh[c], act);
+  }
+}
+
+extern "C" int ff_affine(float* out, int ldo, const float* in, int ldi, long long rows, int C, const float* scale,
+                         const float* shift, int act, void* stream) {
+  FF_CHECK_ARG(out && in && scale && shift && rows > 0 && C > 0 && ldo >= C && ldi >= C, "ff_affine: bad args");
+  long long nb = (rows * C + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(affine_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, out, ldo, in, ldi, rows, C, scale,
+                     shift, act);
+  FF_LAUNCH_CHECK("ff_affine");
+  return FF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n) {   // F.pad(mode='reflect') index map
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+// in [B][C][H][W] -> out [B][Hp][Wp][ldo] channels [0,C): value + add[c]; pad_mode 0 zero / 1 reflect
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C,
+                                                           int H, int W, int Hp, int Wp, int ldo,
+                                                           const float* __restrict__ add, int pad_mode) {
+  const long long total = (long long)B * Hp * Wp * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int x = (int)(t % Wp); t /= Wp;
+    const int y = (int)(t % Hp);
+    const int b = (int)(t / Hp);
+    float v = 0.f;
+    int sy = y, sx = x;
+    bool ok = y < H && x < W;
+    if (!ok && pad_mode == 1) { sy = reflect_idx(y, H); sx = reflect_idx(x, W); ok = true; }
+    if (ok) v = in[(((long long)b * C + c) * H + sy) * W + sx] + (add ? add[c] : 0.f);
+    out[(((long long)b * Hp + y) * Wp + x) * ldo + c] = v;
+  }
+}
+
+extern "C" int ff_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Hp, int Wp, int ldo,
+                               const float* add, int pad_mode, void* stream) {
+  FF_CHECK_ARG(in && out && B > 0 && C > 0 && Hp >= H && Wp >= W && ldo >= C, "ff_nchw_to_nhwc: bad args");
+  FF_CHECK_ARG(pad_mode == 0 || (Hp - H < H && Wp - W < W), "ff_nchw_to_nhwc: reflect pad wider than the image");
+  long long nb = ((long long)B * Hp * Wp * C + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, out, B, C, H, W, Hp, Wp,
+                     ldo, add, pad_mode);
+  FF_LAUNCH_CHECK("ff_nchw_to_nhwc");
+  return FF_OK;
+}
+
+// in [B][Hs][Ws][ldi] channels [0,C) -> out [B][C][H][W] (crop H<=Hs, W<=Ws): (v + add[c]), optional clamp to [0,1]
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C,
+                                                           int H, int W, int Hs, int Ws, int ldi,
+                                                           const float* __restrict__ add, int clamp01) {
+  const long long total = (long long)B * C * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    long long t = i / W;
+    const int y = (int)(t % H); t /= H;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    float v = in[(((long long)b * Hs + y) * Ws + x) * ldi + c] + (add ? add[c] : 0.f);
+    if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+    out[i] = v;
+  }
+}
+
+extern "C" int ff_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, int Hs, int Ws, int ldi,
+                               const float* add, int clamp01, void* stream) {
+  FF_CHECK_ARG(in && out && B > 0 && C > 0 && Hs >= H && Ws >= W && ldi >= C, "ff_nhwc_to_nchw: bad args");
+  long long nb = ((long long)B * C * H * W + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, out, B, C, H, W, Hs, Ws,
+                     ldi, add, clamp01);
+  FF_LAUNCH_CHECK("ff_nhwc_to_nchw");
+  return FF_OK;
+}

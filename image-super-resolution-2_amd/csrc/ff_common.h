@@ -1,0 +1,57 @@
+// Shared helpers for the FreqFusion HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define FF_OK 0
+#define FF_ERR_ARG 1
+#define FF_ERR_LAUNCH 2
+
+extern "C" const char* ff_last_error(void);
+void ff_set_error(const char* fmt, ...);
+
+#define FF_CHECK_ARG(cond, ...)          \
+  do {                                   \
+    if (!(cond)) {                       \
+      ff_set_error(__VA_ARGS__);         \
+      return FF_ERR_ARG;                 \
+    }                                    \
+  } while (0)
+
+#define FF_LAUNCH_CHECK(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      ff_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return FF_ERR_LAUNCH;                                                \
+    }                                                                      \
+  } while (0)
+
+// activation codes shared by every epilogue (include/ff_kernels.h FF_ACT_*)
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_LRELU = 3, ACT_SIGMOID = 4 };
+
+__device__ __forceinline__ float ff_act(float v, int act) {
+  switch (act) {
+    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_LRELU: return v > 0.f ? v : 0.01f * v;
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
+static inline int ff_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Bijective XCD-aware block remap (guide section 5 T1): blocks with equal (bid % 8) share an XCD/L2,
+// so give each XCD a contiguous run of logical tile ids.
+__device__ __forceinline__ int ff_xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}

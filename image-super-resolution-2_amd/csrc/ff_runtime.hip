@@ -1,0 +1,24 @@
+// Error channel + tiny runtime queries of the C-ABI library.
+#include "ff_common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void ff_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* ff_last_error(void) { return g_err; }
+
+extern "C" int ff_abi_version(void) { return 1; }
+
+// Number of compute units of the current device (bench.py sizes its roofline report with it).
+extern "C" int ff_device_cu_count(void) {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+  return n;
+}

@@ -1,0 +1,381 @@
+"""The three frozen experts sequenced on the HIP kernels: HAT-L, DAT, NAFNet-SR.
+
+Each class takes the reference-keyed state dict, prepares device weights once (repacking, BN folding,
+position-bias tables) and exposes forward(lr NCHW [1,3,h,w]) -> SR NCHW [1,3,4h,4w] clamped to [0,1]
+with the semantics of ExpertEnsemble.forward_hat/_dat/_nafnet (src/models/expert_loader.py:591-674):
+reflect-pad to x16, run, crop, clamp.  Activations are NHWC fp32 device tensors; every arithmetic
+step is a libff_hip.so kernel (ops.py), PyTorch only allocates.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .prep import pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv
+
+T = torch.Tensor
+SD = Dict[str, T]
+RGB_MEAN = (0.4488, 0.4371, 0.4040)
+
+
+def _ceil_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+class _Weights:
+    """Small helper: fetch tensors by reference key, move to the device once."""
+
+    def __init__(self, sd: SD, dev, prefix: str):
+        self.sd, self.dev, self.p = sd, dev, prefix
+
+    def __call__(self, name: str) -> T:
+        return self.sd[self.p + name].to(self.dev, torch.float32).contiguous()
+
+    def conv(self, name: str) -> T:
+        return pack_conv(self(name + ".weight"))
+
+    def opt(self, name: str) -> Optional[T]:
+        k = self.p + name
+        return self.sd[k].to(self.dev, torch.float32).contiguous() if k in self.sd else None
+
+
+# =============================================================================================== HAT
+def _rel_index_sa(ws: int) -> T:
+    ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
+    yy, xx = ys.reshape(-1), xs.reshape(-1)
+    return (yy[:, None] - yy[None, :] + ws - 1) * (2 * ws - 1) + (xx[:, None] - xx[None, :] + ws - 1)
+
+
+def _rel_index_oca(ws: int, ows: int) -> T:
+    ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
+    ye, xe = torch.meshgrid(torch.arange(ows), torch.arange(ows), indexing="ij")
+    dy = ye.reshape(-1)[None, :] - ys.reshape(-1)[:, None] + ws - ows + 1
+    dx = xe.reshape(-1)[None, :] - xs.reshape(-1)[:, None] + ws - ows + 1
+    return dy * (ws + ows - 1) + dx
+
+
+class HatHIP:
+    """HAT-L (hat_arch.py:710-984): 12 RHAG x (6 HAB + OCAB), dim 180, 6 heads, window 16."""
+
+    def __init__(self, sd: SD, dev, prefix: str = "expert_ensemble.hat.", groups: int = 12, depth: int = 6, ws: int = 16,
+                 heads: int = 6, conv_scale: float = 0.01):
+        w = _Weights(sd, dev, prefix)
+        self.dev, self.ws, self.heads, self.groups, self.depth, self.conv_scale = dev, ws, heads, groups, depth, conv_scale
+        self.ows = ws + ws // 2
+        self.neg_mean = torch.tensor([-m for m in RGB_MEAN], device=dev)
+        rpi_sa = _rel_index_sa(ws).reshape(-1).to(dev)
+        rpi_oca = _rel_index_oca(ws, self.ows).reshape(-1).to(dev)
+        n, nk = ws * ws, self.ows * self.ows
+
+        def lin(name):
+            return w(name + ".weight"), w(name + ".bias")
+
+        self.conv_first = (w.conv("conv_first"), w("conv_first.bias"))
+        self.pe_norm = (w("patch_embed.norm.weight"), w("patch_embed.norm.bias"))
+        self.blocks: List[List[dict]] = []
+        self.ocab: List[dict] = []
+        self.gconv = []
+        for g in range(groups):
+            blks = []
+            for b in range(depth):
+                q = f"layers.{g}.residual_group.blocks.{b}."
+                tbl = w(q + "attn.relative_position_bias_table")
+                bias = tbl[rpi_sa].reshape(n, n, heads).permute(2, 1, 0).contiguous()      # [heads][key][query]
+                blks.append(dict(
+                    n1=(w(q + "norm1.weight"), w(q + "norm1.bias")), qkv=lin(q + "attn.qkv"), proj=lin(q + "attn.proj"),
+                    bias=bias, cab0=(w.conv(q + "conv_block.cab.0"), w(q + "conv_block.cab.0.bias")),
+                    cab2=(w.conv(q + "conv_block.cab.2"), w(q + "conv_block.cab.2.bias")),
+                    ca1=(w(q + "conv_block.cab.3.attention.1.weight").reshape(-1, 180).contiguous(), w(q + "conv_block.cab.3.attention.1.bias")),
+                    ca2=(w(q + "conv_block.cab.3.attention.3.weight").reshape(180, -1).contiguous(), w(q + "conv_block.cab.3.attention.3.bias")),
+                    n2=(w(q + "norm2.weight"), w(q + "norm2.bias")), fc1=lin(q + "mlp.fc1"), fc2=lin(q + "mlp.fc2"),
+                    shift=0 if b % 2 == 0 else ws // 2))
+            self.blocks.append(blks)
+            q = f"layers.{g}.residual_group.overlap_attn."
+            tbl = w(q + "relative_position_bias_table")
+            self.ocab.append(dict(
+                n1=(w(q + "norm1.weight"), w(q + "norm1.bias")), qkv=lin(q + "qkv"), proj=lin(q + "proj"),
+                bias=tbl[rpi_oca].reshape(n, nk, heads).permute(2, 1, 0).contiguous(),
+                n2=(w(q + "norm2.weight"), w(q + "norm2.bias")), fc1=lin(q + "mlp.fc1"), fc2=lin(q + "mlp.fc2")))
+            self.gconv.append((w.conv(f"layers.{g}.conv"), w(f"layers.{g}.conv.bias")))
+        self.norm = (w("norm.weight"), w("norm.bias"))
+        self.after = (w.conv("conv_after_body"), w("conv_after_body.bias"))
+        self.before_up = (w.conv("conv_before_upsample.0"), w("conv_before_upsample.0.bias"))
+        self.up0 = (w.conv("upsample.0"), w("upsample.0.bias"))
+        self.up2 = (w.conv("upsample.2"), w("upsample.2.bias"))
+        self.last = (w.conv("conv_last"), (w("conv_last.bias") - self.neg_mean).contiguous())   # "+ mean" folded into the bias
+
+    # -- blocks -------------------------------------------------------------------------------
+    def _mlp(self, x: T, blk: dict) -> T:
+        xn = ops.layernorm(x, *blk["n2"])
+        h = ops.linear(xn, *blk["fc1"], act="gelu")
+        return ops.linear(h, *blk["fc2"], res=x)
+
+    def hab(self, x: T, blk: dict) -> T:
+        _, H, W, C = x.shape
+        d = C // self.heads
+        xn = ops.layernorm(x, *blk["n1"])
+        qkv = ops.linear(xn, *blk["qkv"])
+        att = torch.empty_like(x)
+        s = blk["shift"]
+        ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
+                        kwin=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, heads=self.heads, d=d, scale=d ** -0.5)
+        c1 = ops.conv2d(xn, *blk["cab0"], ksize=(3, 3), pad=(1, 1), act="gelu")
+        c2 = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1))
+        gate = ops.vec_mlp(ops.pool_mean(c2), *blk["ca1"], "relu", *blk["ca2"], "sigmoid", post=self.conv_scale)
+        t = ops.mix2(x, c2, cb=gate)                               # shortcut + conv_x * conv_scale
+        x = ops.linear(att, *blk["proj"], res=t)                   # + proj(attention)
+        return self._mlp(x, blk)
+
+    def ocab_block(self, x: T, blk: dict) -> T:
+        _, H, W, C = x.shape
+        d = C // self.heads
+        xn = ops.layernorm(x, *blk["n1"])
+        qkv = ops.linear(xn, *blk["qkv"])
+        att = torch.empty_like(x)
+        ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
+                        kwin=(self.ows, self.ows), shift=(0, 0), use_mask=False, heads=self.heads, d=d, scale=d ** -0.5)
+        x = ops.linear(att, *blk["proj"], res=x)
+        return self._mlp(x, blk)
+
+    def group(self, x: T, g: int) -> T:
+        y = x
+        for blk in self.blocks[g]:
+            y = self.hab(y, blk)
+        y = self.ocab_block(y, self.ocab[g])
+        return ops.conv2d(y, *self.gconv[g], ksize=(3, 3), pad=(1, 1), res=x)
+
+    def _tail(self, x: T) -> T:
+        x = ops.conv2d(x, *self.before_up, ksize=(3, 3), pad=(1, 1), act="lrelu")
+        x = ops.conv2d(x, *self.up0, ksize=(3, 3), pad=(1, 1), shuffle=2)
+        x = ops.conv2d(x, *self.up2, ksize=(3, 3), pad=(1, 1), shuffle=2)
+        return ops.conv2d(x, *self.last, ksize=(3, 3), pad=(1, 1))
+
+    def forward(self, lr: T, taps: Optional[dict] = None) -> T:
+        _, _, h, w = lr.shape
+        Hp, Wp = _ceil_to(h, self.ws), _ceil_to(w, self.ws)
+        xin = ops.nchw_to_nhwc(lr, Hp, Wp, add=self.neg_mean, pad_mode="reflect")
+        feat = ops.conv2d(xin, *self.conv_first, ksize=(3, 3), pad=(1, 1))
+        x = ops.layernorm(feat, *self.pe_norm)
+        for g in range(self.groups):
+            if taps is not None and g == 0:
+                y = x
+                for b, blk in enumerate(self.blocks[0]):
+                    y = self.hab(y, blk)
+                    taps[f"hat.g0.b{b}"] = y
+                y = self.ocab_block(y, self.ocab[0])
+                taps["hat.g0.ocab"] = y
+                x = ops.conv2d(y, *self.gconv[0], ksize=(3, 3), pad=(1, 1), res=x)
+                taps["hat.g0.out"] = x
+            else:
+                x = self.group(x, g)
+        x = ops.layernorm(x, *self.norm)
+        x = ops.conv2d(x, *self.after, ksize=(3, 3), pad=(1, 1), res=feat)
+        sr = self._tail(x)
+        return ops.nhwc_to_nchw(sr, 4 * h, 4 * w, clamp01=True)
+
+
+# =============================================================================================== DAT
+def _dat_dpb_bias(sd: SD, p: str, hs: int, wsz: int, heads: int) -> T:
+    """DynamicPosBias (dat_arch.py:177-212) is input independent: evaluate it once on the host."""
+    import torch.nn.functional as F
+    ys, xs = torch.meshgrid(torch.arange(1 - hs, hs), torch.arange(1 - wsz, wsz), indexing="ij")
+    t = F.linear(torch.stack([ys.reshape(-1), xs.reshape(-1)], dim=1).float(), sd[p + ".pos_proj.weight"].float().cpu(),
+                 sd[p + ".pos_proj.bias"].float().cpu())
+    for j in ("pos1", "pos2", "pos3"):
+        t = F.layer_norm(t, (t.shape[-1],), sd[f"{p}.{j}.0.weight"].float().cpu(), sd[f"{p}.{j}.0.bias"].float().cpu())
+        t = F.linear(F.relu(t), sd[f"{p}.{j}.2.weight"].float().cpu(), sd[f"{p}.{j}.2.bias"].float().cpu())
+    cy, cx = torch.meshgrid(torch.arange(hs), torch.arange(wsz), indexing="ij")
+    cy, cx = cy.reshape(-1), cx.reshape(-1)
+    idx = (cy[:, None] - cy[None, :] + hs - 1) * (2 * wsz - 1) + (cx[:, None] - cx[None, :] + wsz - 1)
+    n = hs * wsz
+    return t[idx.reshape(-1)].reshape(n, n, heads).permute(2, 1, 0).contiguous()            # [heads][key][query]
+
+
+def dat_should_shift(g: int, b: int) -> bool:
+    return (g % 2 == 0 and b > 0 and (b - 2) % 4 == 0) or (g % 2 != 0 and b % 4 == 0)
+
+
+class DatHIP:
+    """DAT (dat_arch.py:864-1028): 6 residual groups x 6 DATB (spatial / channel alternating), dim 180."""
+
+    def __init__(self, sd: SD, dev, prefix: str = "expert_ensemble.dat.", groups: int = 6, depth: int = 6, split=(8, 32),
+                 heads: int = 6):
+        w = _Weights(sd, dev, prefix)
+        self.dev, self.groups, self.depth, self.split, self.heads = dev, groups, depth, split, heads
+        self.neg_mean = torch.tensor([-m for m in RGB_MEAN], device=dev)
+        C = 180
+
+        def lin(name):
+            return w(name + ".weight"), w(name + ".bias")
+
+        def folded_1x1(conv, bn, cin):
+            wt = w(conv + ".weight").reshape(-1, cin)
+            sc, sh = bn_scale_shift({k: v.to(dev) for k, v in sd.items() if k.startswith(prefix + bn)}, prefix + bn)
+            return fold_bn_after_conv(wt, w(conv + ".bias"), sc, sh)
+
+        self.conv_first = (w.conv("conv_first"), w("conv_first.bias"))
+        self.before = (w("before_RG.1.weight"), w("before_RG.1.bias"))
+        self.blocks: List[List[dict]] = []
+        self.gconv = []
+        for g in range(groups):
+            blks = []
+            for b in range(depth):
+                q = f"layers.{g}.blocks.{b}."
+                sc, sh = bn_scale_shift({k: v.to(dev) for k, v in sd.items() if k.startswith(prefix + q + "attn.dwconv.1")},
+                                        prefix + q + "attn.dwconv.1")
+                ci1 = folded_1x1(q + "attn.channel_interaction.1", q + "attn.channel_interaction.2", C)
+                si0 = folded_1x1(q + "attn.spatial_interaction.0", q + "attn.spatial_interaction.1", C)
+                blk = dict(
+                    spatial=(b % 2 == 0), shifted=dat_should_shift(g, b),
+                    n1=(w(q + "norm1.weight"), w(q + "norm1.bias")), qkv=lin(q + "attn.qkv"), proj=lin(q + "attn.proj"),
+                    dw=(pack_dw(w(q + "attn.dwconv.0.weight")), w(q + "attn.dwconv.0.bias"), sc, sh),
+                    ci1=ci1, ci4=(w(q + "attn.channel_interaction.4.weight").reshape(C, -1).contiguous(), w(q + "attn.channel_interaction.4.bias")),
+                    si0=si0, si3=(w(q + "attn.spatial_interaction.3.weight").reshape(1, -1).contiguous(), w(q + "attn.spatial_interaction.3.bias")),
+                    n2=(w(q + "norm2.weight"), w(q + "norm2.bias")), fc1=lin(q + "ffn.fc1"),
+                    sgn=(w(q + "ffn.sg.norm.weight"), w(q + "ffn.sg.norm.bias")),
+                    sgc=(pack_dw(w(q + "ffn.sg.conv.weight")), w(q + "ffn.sg.conv.bias")), fc2=lin(q + "ffn.fc2"))
+                if blk["spatial"]:
+                    blk["bias"] = [
+                        _dat_dpb_bias(sd, prefix + q + "attn.attns.0.pos", split[0], split[1], heads // 2).to(dev),
+                        _dat_dpb_bias(sd, prefix + q + "attn.attns.1.pos", split[1], split[0], heads // 2).to(dev)]
+                else:
+                    blk["temp"] = w(q + "attn.temperature").reshape(-1).contiguous()
+                blks.append(blk)
+            self.blocks.append(blks)
+            self.gconv.append((w.conv(f"layers.{g}.conv"), w(f"layers.{g}.conv.bias")))
+        self.norm = (w("norm.weight"), w("norm.bias"))
+        self.after = (w.conv("conv_after_body"), w("conv_after_body.bias"))
+        self.before_up = (w.conv("conv_before_upsample.0"), w("conv_before_upsample.0.bias"))
+        self.up0 = (w.conv("upsample.0"), w("upsample.0.bias"))
+        self.up2 = (w.conv("upsample.2"), w("upsample.2.bias"))
+        self.last = (w.conv("conv_last"), (w("conv_last.bias") - self.neg_mean).contiguous())
+
+    def block(self, x: T, blk: dict) -> T:
+        _, H, W, C = x.shape
+        half, hh = C // 2, self.heads // 2
+        d = half // hh
+        xn = ops.layernorm(x, *blk["n1"])
+        qkv = ops.linear(xn, *blk["qkv"])                                        # [1,H,W,3C] = q | k | v
+        v = qkv[..., 2 * C:]
+        conv_x = ops.dwconv2d(v, blk["dw"][0], blk["dw"][1], post_scale=blk["dw"][2], post_shift=blk["dw"][3], act="gelu")
+        if blk["spatial"]:
+            m = max(self.split)
+            Hp, Wp = _ceil_to(H, m), _ceil_to(W, m)
+            att = torch.empty_like(x)
+            for br in range(2):
+                wh, ww = (self.split[0], self.split[1]) if br == 0 else (self.split[1], self.split[0])
+                sh = (wh // 2, ww // 2) if blk["shifted"] else (0, 0)
+                ops.window_attn(qkv, att, blk["bias"][br], q_off=br * half, k_off=C + br * half, v_off=2 * C + br * half,
+                                o_off=br * half, H=H, W=W, Hp=Hp, Wp=Wp, win=(wh, ww), kwin=(wh, ww), shift=sh,
+                                use_mask=blk["shifted"], heads=hh, d=d, scale=d ** -0.5)
+            ch_in, sp_in = conv_x, att
+        else:
+            wbd = ops.chan_attn_weights(qkv, 0, C, blk["temp"])
+            att = ops.linear(v, wbd)
+            ch_in, sp_in = att, conv_x
+        cm = ops.vec_mlp(ops.pool_mean(ch_in), *blk["ci1"], "gelu", *blk["ci4"], "sigmoid")              # [1,C]
+        sm = ops.linear(ops.linear(sp_in, *blk["si0"], act="gelu"), *blk["si3"], act="sigmoid")          # [1,H,W,1]
+        if blk["spatial"]:
+            fused = ops.mix2(att, conv_x, ca=cm, pb=sm)
+        else:
+            fused = ops.mix2(att, conv_x, pa=sm, cb=cm)
+        x = ops.linear(fused, *blk["proj"], res=x)
+        # SGFN
+        xn = ops.layernorm(x, *blk["n2"])
+        y = ops.linear(xn, *blk["fc1"], act="gelu")
+        c2 = y.shape[-1] // 2
+        gte = ops.layernorm(y[..., c2:], *blk["sgn"])
+        gte = ops.dwconv2d(gte, *blk["sgc"])
+        z = ops.fma3(None, y[..., :c2], gte)
+        return ops.linear(z, *blk["fc2"], res=x)
+
+    def forward(self, lr: T, taps: Optional[dict] = None) -> T:
+        _, _, h, w = lr.shape
+        Hp, Wp = _ceil_to(h, 16), _ceil_to(w, 16)
+        xin = ops.nchw_to_nhwc(lr, Hp, Wp, add=self.neg_mean, pad_mode="reflect")
+        feat = ops.conv2d(xin, *self.conv_first, ksize=(3, 3), pad=(1, 1))
+        x = ops.layernorm(feat, *self.before)
+        for g in range(self.groups):
+            y = x
+            for b, blk in enumerate(self.blocks[g]):
+                y = self.block(y, blk)
+                if taps is not None and g < 2:
+                    taps[f"dat.g{g}.b{b}"] = y
+            x = ops.conv2d(y, *self.gconv[g], ksize=(3, 3), pad=(1, 1), res=x)
+        x = ops.layernorm(x, *self.norm)
+        x = ops.conv2d(x, *self.after, ksize=(3, 3), pad=(1, 1), res=feat)
+        x = ops.conv2d(x, *self.before_up, ksize=(3, 3), pad=(1, 1), act="lrelu")
+        x = ops.conv2d(x, *self.up0, ksize=(3, 3), pad=(1, 1), shuffle=2)
+        x = ops.conv2d(x, *self.up2, ksize=(3, 3), pad=(1, 1), shuffle=2)
+        sr = ops.conv2d(x, *self.last, ksize=(3, 3), pad=(1, 1))
+        return ops.nhwc_to_nchw(sr, 4 * h, 4 * w, clamp01=True)
+
+
+# =============================================================================================== NAFNet-SR
+class NafnetHIP:
+    """NAFNetSR (nafnet/__init__.py:117-139 + nafnet_arch.py:137-225): bicubic x4, then the width-64
+    UNet (enc 2/2/4/8, mid 12, dec 2/2/2/2) at HR resolution."""
+
+    def __init__(self, sd: SD, dev, prefix: str = "expert_ensemble.nafnet.nafnet.", enc=(2, 2, 4, 8), mid: int = 12,
+                 dec=(2, 2, 2, 2)):
+        w = _Weights(sd, dev, prefix)
+        self.dev, self.enc_n, self.mid_n, self.dec_n = dev, enc, mid, dec
+
+        def blk(q):
+            def c1(n):
+                wt = w(q + n + ".weight")
+                return wt.reshape(wt.shape[0], wt.shape[1]).contiguous(), w(q + n + ".bias")
+            return dict(n1=(w(q + "norm1.weight"), w(q + "norm1.bias")), n2=(w(q + "norm2.weight"), w(q + "norm2.bias")),
+                        c1=c1("conv1"), c2=(pack_dw(w(q + "conv2.weight")), w(q + "conv2.bias")), c3=c1("conv3"),
+                        sca=c1("sca.1"), c4=c1("conv4"), c5=c1("conv5"),
+                        beta=w(q + "beta").reshape(-1).contiguous(), gamma=w(q + "gamma").reshape(-1).contiguous())
+
+        self.intro = (w.conv("intro"), w("intro.bias"))
+        self.ending = (w.conv("ending"), w("ending.bias"))
+        self.encs = [[blk(f"encoders.{l}.{b}.") for b in range(n)] for l, n in enumerate(enc)]
+        self.mids = [blk(f"middle_blks.{b}.") for b in range(mid)]
+        self.decs = [[blk(f"decoders.{l}.{b}.") for b in range(n)] for l, n in enumerate(dec)]
+        self.downs = [(w.conv(f"downs.{l}"), w(f"downs.{l}.bias")) for l in range(len(enc))]
+        self.ups = [w(f"ups.{l}.0.weight").reshape(w(f"ups.{l}.0.weight").shape[0], -1).contiguous() for l in range(len(dec))]
+
+    def block(self, x: T, k: dict) -> T:
+        c = x.shape[-1]
+        t = ops.layernorm(x, *k["n1"], eps=1e-6)
+        t = ops.linear(t, *k["c1"])
+        t = ops.dwconv2d(t, *k["c2"])
+        g = ops.fma3(None, t[..., :c], t[..., c:])                          # SimpleGate
+        sca = ops.vec_mlp(ops.pool_mean(g), *k["sca"], None)                # [1,c]
+        w3 = ops.mix2(k["c3"][0], ca=sca.reshape(-1))                       # conv3(g * sca) == (W3 . diag(sca)) g
+        y = ops.linear(g, w3, k["c3"][1], res=x, mul=k["beta"])
+        t = ops.linear(ops.layernorm(y, *k["n2"], eps=1e-6), *k["c4"])
+        g = ops.fma3(None, t[..., :c], t[..., c:])
+        return ops.linear(g, *k["c5"], res=y, mul=k["gamma"])
+
+    def forward(self, lr: T, taps: Optional[dict] = None) -> T:
+        _, _, h, w = lr.shape
+        H, W = 4 * h, 4 * w
+        m = 2 ** len(self.enc_n)
+        Hp, Wp = _ceil_to(H, m), _ceil_to(W, m)
+        inp = torch.zeros((1, Hp, Wp, 3), device=lr.device, dtype=torch.float32)
+        ops.resize(lr, (H, W), mode="bicubic", scale_factor=4.0, layout="nchw", out=inp)
+        x = ops.conv2d(inp, *self.intro, ksize=(3, 3), pad=(1, 1))
+        skips = []
+        for lvl, blks in enumerate(self.encs):
+            for b, k in enumerate(blks):
+                x = self.block(x, k)
+                if taps is not None and lvl == 0:
+                    taps[f"naf.enc0.b{b}"] = x
+            skips.append(x)
+            x = ops.conv2d(x, *self.downs[lvl], ksize=(2, 2), stride=(2, 2), pad=(0, 0))
+        for k in self.mids:
+            x = self.block(x, k)
+        if taps is not None:
+            taps["naf.mid"] = x
+        for lvl, blks in enumerate(self.decs):
+            x = ops.conv2d(x, self.ups[lvl], None, shuffle=2, res=skips[-1 - lvl])
+            for k in blks:
+                x = self.block(x, k)
+        x = ops.conv2d(x, *self.ending, ksize=(3, 3), pad=(1, 1), res=inp)
+        return ops.nhwc_to_nchw(x, H, W, clamp01=True)

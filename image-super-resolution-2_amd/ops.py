@@ -1,0 +1,391 @@
+"""Torch-tensor front-end of the C ABI (include/ff_kernels.h).
+
+PyTorch is plumbing here: it owns device memory and the stream.  Every function below only validates
+shapes/strides and forwards raw pointers to libff_hip.so; there is no PyTorch compute fallback -- a
+missing library or a CPU tensor raises.
+Tensors are fp32, channel-last.  "rows view": any tensor whose last dim is contiguous and whose
+leading dims collapse to a single row stride (e.g. a channel slice t[..., a:b] of an NHWC buffer).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as _lib
+
+ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2, "lrelu": 3, "sigmoid": 4}
+T = torch.Tensor
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: T, name: str):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32:
+        raise _lib.FFError(f"{name}: expected a CUDA(HIP) float32 tensor")
+
+
+def _ptr(t: Optional[T]) -> Optional[int]:
+    if t is None:
+        return None
+    _chk(t, "arg")
+    return t.data_ptr()
+
+
+def rows_view(t: T, name: str = "tensor") -> Tuple[int, int, int, int]:
+    """-> (ptr, ld, rows, C) for a tensor whose leading dims collapse to rows of stride ld."""
+    _chk(t, name)
+    if t.dim() == 1:
+        return t.data_ptr(), t.shape[0], 1, t.shape[0]
+    if t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise _lib.FFError(f"{name}: last dim must be contiguous")
+    ld = t.stride(-2)
+    rows = 1
+    expect = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != expect:
+            raise _lib.FFError(f"{name}: leading dims do not collapse to a constant row stride {tuple(t.shape)} {t.stride()}")
+        expect = expect * t.shape[d]
+        rows *= t.shape[d]
+    return t.data_ptr(), ld, rows, t.shape[-1]
+
+
+def _nhwc(t: T, name: str):
+    """-> (ptr, ld, B, H, W, C) for a 4-D NHWC rows view."""
+    if t.dim() != 4:
+        raise _lib.FFError(f"{name}: expected [B,H,W,C]")
+    p, ld, rows, c = rows_view(t, name)
+    return p, ld, t.shape[0], t.shape[1], t.shape[2], c
+
+
+def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1), pad=(0, 0), act=None,
+           res: Optional[T] = None, mul: Optional[T] = None, alpha: float = 1.0, shuffle: int = 0,
+           out: Optional[T] = None, tile_hint: int = 0) -> T:
+    """x [B,H,W,Cin] (rows view), w packed [Cout, KH*KW*Cin] -> [B,Ho,Wo,Cout] (or pixel-shuffled)."""
+    xp, ldi, B, H, W, Cin = _nhwc(x, "conv2d.x")
+    KH, KW = ksize
+    Cout = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != KH * KW * Cin or not w.is_contiguous():
+        raise _lib.FFError(f"conv2d: packed weight must be [Cout, {KH * KW * Cin}], got {tuple(w.shape)}")
+    Ho = (H + 2 * pad[0] - KH) // stride[0] + 1
+    Wo = (W + 2 * pad[1] - KW) // stride[1] + 1
+    oshape = (B, Ho * 2, Wo * 2, Cout // 4) if shuffle == 2 else (B, Ho, Wo, Cout)
+    if out is None:
+        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != oshape:
+        raise _lib.FFError(f"conv2d: out shape {tuple(out.shape)} != {oshape}")
+    op, ldo, *_ = _nhwc(out, "conv2d.out")
+    rp, ldr = None, 0
+    if res is not None:
+        if tuple(res.shape) != oshape:
+            raise _lib.FFError(f"conv2d: res shape {tuple(res.shape)} != {oshape}")
+        rp, ldr, *_ = _nhwc(res, "conv2d.res")
+    _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, B, H, W, Cin, ldi, Ho, Wo, Cout, ldo, ldr,
+                              KH, KW, stride[0], stride[1], pad[0], pad[1], ACT[act], float(alpha), shuffle, tile_hint,
+                              _stream()))
+    return out
+
+
+def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] = None, mul: Optional[T] = None,
+           alpha: float = 1.0, out: Optional[T] = None) -> T:
+    """x [..., K] rows view, w [N, K] -> [..., N]."""
+    xp, ldi, rows, K = rows_view(x, "linear.x")
+    N = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != K or not w.is_contiguous():
+        raise _lib.FFError(f"linear: weight must be [N, {K}], got {tuple(w.shape)}")
+    oshape = tuple(x.shape[:-1]) + (N,)
+    if out is None:
+        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+    op, ldo, orows, oc = rows_view(out, "linear.out")
+    if orows != rows or oc != N:
+        raise _lib.FFError("linear: out shape mismatch")
+    rp, ldr = None, 0
+    if res is not None:
+        rp, ldr, rrows, rc = rows_view(res, "linear.res")
+        if rrows != rows or rc != N:
+            raise _lib.FFError("linear: res shape mismatch")
+    _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, 1, 1, rows, K, ldi, 1, rows, N, ldo, ldr,
+                              1, 1, 1, 1, 0, 0, ACT[act], float(alpha), 0, 0, _stream()))
+    return out
+
+
+def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int, o_off: int, H: int, W: int, Hp: int,
+                Wp: int, win: Tuple[int, int], kwin: Tuple[int, int], shift: Tuple[int, int], use_mask: bool, heads: int,
+                d: int, scale: float) -> T:
+    qp, ldq, B, h_, w_, _ = _nhwc(qkv, "window_attn.qkv")
+    op, ldo, *_ = _nhwc(out, "window_attn.out")
+    if (h_, w_) != (H, W) or tuple(out.shape[:3]) != (B, H, W):
+        raise _lib.FFError("window_attn: qkv/out spatial dims mismatch")
+    nk = kwin[0] * kwin[1]
+    if tuple(biasT.shape) != (heads, nk, 256) or not biasT.is_contiguous():
+        raise _lib.FFError(f"window_attn: biasT must be [{heads},{nk},256]")
+    if q_off + heads * d > qkv.shape[-1] or k_off + heads * d > qkv.shape[-1] or v_off + heads * d > qkv.shape[-1] \
+            or o_off + heads * d > out.shape[-1]:
+        raise _lib.FFError("window_attn: channel offsets out of range")
+    _lib.check(_L().ff_window_attn(qp, ldq, q_off, k_off, v_off, op, ldo, o_off, biasT.data_ptr(), B, H, W, Hp, Wp, win[0],
+                                   win[1], kwin[0], kwin[1], shift[0], shift[1], int(use_mask), heads, d, float(scale),
+                                   _stream()))
+    return out
+
+
+def layernorm(x: T, gamma: T, beta: T, eps: float = 1e-5, out: Optional[T] = None) -> T:
+    xp, ldi, rows, C = rows_view(x, "layernorm.x")
+    if out is None:
+        out = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
+    op, ldo, orows, oc = rows_view(out, "layernorm.out")
+    if orows != rows or oc != C or gamma.numel() != C or beta.numel() != C:
+        raise _lib.FFError("layernorm: shape mismatch")
+    _lib.check(_L().ff_layernorm(xp, ldi, op, ldo, rows, C, gamma.data_ptr(), beta.data_ptr(), float(eps), _stream()))
+    return out
+
+
+def pool_mean(x: T) -> T:
+    """[B,H,W,C] rows view -> [B,C]."""
+    xp, ld, B, H, W, C = _nhwc(x, "pool_mean.x")
+    P = H * W
+    nwork = int(_L().ff_pool_mean_workspace(B, P, C))
+    work = torch.empty(nwork, device=x.device, dtype=torch.float32)
+    out = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    _lib.check(_L().ff_pool_mean(xp, ld, B, P, C, out.data_ptr(), work.data_ptr(), nwork, _stream()))
+    return out
+
+
+def vec_mlp(v: T, W1: T, b1: Optional[T], act1, W2: Optional[T] = None, b2: Optional[T] = None, act2=None,
+            post: float = 1.0) -> T:
+    B, Cin = v.shape
+    Ch = W1.shape[0]
+    Cout = W2.shape[0] if W2 is not None else Ch
+    if W1.shape[1] != Cin or (W2 is not None and W2.shape[1] != Ch):
+        raise _lib.FFError("vec_mlp: weight shape mismatch")
+    out = torch.empty((B, Cout), device=v.device, dtype=torch.float32)
+    _lib.check(_L().ff_vec_mlp(v.data_ptr(), B, Cin, W1.data_ptr(), _ptr(b1), Ch, ACT[act1], _ptr(W2), _ptr(b2), Cout,
+                               ACT[act2], float(post), out.data_ptr(), _stream()))
+    return out
+
+
+def dwconv2d(x: T, w_tap: T, bias: Optional[T] = None, *, ksize=(3, 3), stride=(1, 1), pad=(1, 1),
+             post_scale: Optional[T] = None, post_shift: Optional[T] = None, act=None, out: Optional[T] = None) -> T:
+    xp, ldi, B, H, W, C = _nhwc(x, "dwconv2d.x")
+    KH, KW = ksize
+    if tuple(w_tap.shape) != (KH * KW, C) or not w_tap.is_contiguous():
+        raise _lib.FFError(f"dwconv2d: tap-major weight must be [{KH * KW},{C}]")
+    Ho = (H + 2 * pad[0] - KH) // stride[0] + 1
+    Wo = (W + 2 * pad[1] - KW) // stride[1] + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.float32)
+    op, ldo, *_ = _nhwc(out, "dwconv2d.out")
+    _lib.check(_L().ff_dwconv2d(xp, ldi, op, ldo, B, H, W, C, Ho, Wo, w_tap.data_ptr(), _ptr(bias), KH, KW, stride[0],
+                                stride[1], pad[0], pad[1], _ptr(post_scale), _ptr(post_shift), ACT[act], _stream()))
+    return out
+
+
+def mix2(a: T, b: Optional[T] = None, *, ka: float = 1.0, kb: float = 1.0, ca: Optional[T] = None,
+         cb: Optional[T] = None, pa: Optional[T] = None, pb: Optional[T] = None, clamp01: bool = False,
+         out: Optional[T] = None) -> T:
+    ap, lda, rows, C = rows_view(a, "mix2.a")
+    bp, ldb = None, 0
+    if b is not None:
+        bp, ldb, brows, bc = rows_view(b, "mix2.b")
+        if brows != rows or bc != C:
+            raise _lib.FFError("mix2: a/b shape mismatch")
+    if out is None:
+        out = torch.empty(tuple(a.shape), device=a.device, dtype=torch.float32)
+    op, ldo, orows, oc = rows_view(out, "mix2.out")
+    if orows != rows or oc != C:
+        raise _lib.FFError("mix2: out shape mismatch")
+
+    def pvec(p, nm):
+        if p is None:
+            return None, 0
+        pp, ldp, prows, pc = rows_view(p, nm)
+        if prows != rows or pc != 1:
+            raise _lib.FFError(f"{nm}: per-row vector must be [rows,1]")
+        return pp, ldp
+
+    pap, ldpa = pvec(pa, "mix2.pa")
+    pbp, ldpb = pvec(pb, "mix2.pb")
+    for v_, nm in ((ca, "ca"), (cb, "cb")):
+        if v_ is not None and v_.numel() != C:
+            raise _lib.FFError(f"mix2: {nm} must have {C} elements")
+    _lib.check(_L().ff_mix2(op, ldo, ap, lda, bp, ldb, rows, C, float(ka), float(kb), _ptr(ca), _ptr(cb), pap, ldpa, pbp,
+                            ldpb, int(clamp01), _stream()))
+    return out
+
+
+def fma3(a: Optional[T], b: T, c: T, alpha: float = 1.0, out: Optional[T] = None) -> T:
+    bp, ldb, rows, C = rows_view(b, "fma3.b")
+    cp, ldc, crows, cc = rows_view(c, "fma3.c")
+    if crows != rows or cc != C:
+        raise _lib.FFError("fma3: b/c shape mismatch")
+    ap, lda = None, 0
+    if a is not None:
+        ap, lda, arows, ac = rows_view(a, "fma3.a")
+        if arows != rows or ac != C:
+            raise _lib.FFError("fma3: a shape mismatch")
+    if out is None:
+        out = torch.empty(tuple(b.shape), device=b.device, dtype=torch.float32)
+    op, ldo, orows, oc = rows_view(out, "fma3.out")
+    if orows != rows or oc != C:
+        raise _lib.FFError("fma3: out shape mismatch")
+    _lib.check(_L().ff_fma3(op, ldo, ap, lda, bp, ldb, cp, ldc, rows, C, float(alpha), _stream()))
+    return out
+
+
+def affine(x: T, scale: T, shift: T, act=None, out: Optional[T] = None) -> T:
+    xp, ldi, rows, C = rows_view(x, "affine.x")
+    if out is None:
+        out = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
+    op, ldo, orows, oc = rows_view(out, "affine.out")
+    if orows != rows or oc != C or scale.numel() != C or shift.numel() != C:
+        raise _lib.FFError("affine: shape mismatch")
+    _lib.check(_L().ff_affine(op, ldo, xp, ldi, rows, C, scale.data_ptr(), shift.data_ptr(), ACT[act], _stream()))
+    return out
+
+
+def nchw_to_nhwc(x: T, Hp: Optional[int] = None, Wp: Optional[int] = None, add: Optional[T] = None,
+                 pad_mode: str = "zero", out: Optional[T] = None) -> T:
+    _chk(x, "nchw_to_nhwc.x")
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    Hp, Wp = Hp or H, Wp or W
+    if out is None:
+        out = torch.empty((B, Hp, Wp, C), device=x.device, dtype=torch.float32)
+    op, ldo, *_ = _nhwc(out, "nchw_to_nhwc.out")
+    _lib.check(_L().ff_nchw_to_nhwc(x.data_ptr(), op, B, C, H, W, Hp, Wp, ldo, _ptr(add), 1 if pad_mode == "reflect" else 0,
+                                    _stream()))
+    return out
+
+
+def nhwc_to_nchw(x: T, H: Optional[int] = None, W: Optional[int] = None, add: Optional[T] = None, clamp01: bool = False) -> T:
+    xp, ldi, B, Hs, Ws, C = _nhwc(x, "nhwc_to_nchw.x")
+    H, W = H or Hs, W or Ws
+    out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(_L().ff_nhwc_to_nchw(xp, out.data_ptr(), B, C, H, W, Hs, Ws, ldi, _ptr(add), int(clamp01), _stream()))
+    return out
+
+
+def _aten_scale(n_in: int, n_out: int, scale_factor: Optional[float]) -> float:
+    """ATen area_pixel_compute_scale (align_corners=False): 1/scale_factor if given else in/out, in fp32."""
+    import numpy as np
+    if scale_factor is not None and scale_factor > 0:
+        return float(np.float32(1.0) / np.float32(scale_factor))
+    return float(np.float32(n_in) / np.float32(n_out))
+
+
+def resize(x: T, size: Tuple[int, int], *, mode: str = "bilinear", scale_factor: Optional[float] = None,
+           layout: str = "nhwc", out: Optional[T] = None, mul: float = 1.0) -> T:
+    """x NHWC rows view [B,H,W,C] or planar [B,C,H,W] (layout='nchw'); out is always NHWC (may be a channel slice)."""
+    Ho, Wo = size
+    if layout == "nhwc":
+        xp, ld, B, Hi, Wi, C = _nhwc(x, "resize.x")
+        isb, isc, isy, isx = Hi * Wi * ld, 1, Wi * ld, ld
+    else:
+        _chk(x, "resize.x")
+        x = x.contiguous()
+        B, C, Hi, Wi = x.shape
+        xp = x.data_ptr()
+        isb, isc, isy, isx = C * Hi * Wi, Hi * Wi, Wi, 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.float32)
+    op, ldo, ob, oh, ow, oc = _nhwc(out, "resize.out")      # out may be larger than (Ho, Wo): the top-left region is written
+    if ob != B or oc != C or oh < Ho or ow < Wo:
+        raise _lib.FFError("resize: out shape mismatch")
+    sh = _aten_scale(Hi, Ho, scale_factor)
+    sw = _aten_scale(Wi, Wo, scale_factor)
+    _lib.check(_L().ff_resize(xp, isb, isc, isy, isx, Hi, Wi, op, oh * ow * ldo, 1, ow * ldo, ldo, Ho, Wo, B, C, sh, sw,
+                              0 if mode == "bilinear" else 1, float(mul), _stream()))
+    return out
+
+
+def avgpool2(x: T) -> T:
+    xp, ldi, B, H, W, C = _nhwc(x, "avgpool2.x")
+    out = torch.empty((B, H // 2, W // 2, C), device=x.device, dtype=torch.float32)
+    _lib.check(_L().ff_avgpool2(xp, ldi, out.data_ptr(), C, B, H, W, C, _stream()))
+    return out
+
+
+def dct8_bands(x_planar: T, dct_mat: T, masks3: T, band_scale: T, out: T, ch_off: int):
+    _chk(x_planar, "dct8_bands.x")
+    C, H, W = x_planar.shape
+    op, ldo, *_ = _nhwc(out, "dct8_bands.out")
+    _lib.check(_L().ff_dct8_bands(x_planar.data_ptr(), C, H, W, dct_mat.data_ptr(), masks3.data_ptr(), band_scale.data_ptr(),
+                                  op, ldo, ch_off, _stream()))
+
+
+def dwt_pass(x_planar: T, axis: int, lo8: T, hi8: T) -> Tuple[T, T]:
+    _chk(x_planar, "dwt_pass.x")
+    C, H, W = x_planar.shape
+    Ho = (H + 6) // 2 + 1 if axis == 0 else H
+    Wo = (W + 6) // 2 + 1 if axis == 1 else W
+    lo = torch.empty((C, Ho, Wo), device=x_planar.device, dtype=torch.float32)
+    hi = torch.empty_like(lo)
+    _lib.check(_L().ff_dwt_pass(x_planar.data_ptr(), C, H, W, axis, lo8.data_ptr(), hi8.data_ptr(), lo.data_ptr(),
+                                hi.data_ptr(), _stream()))
+    return lo, hi
+
+
+def fft_bands(x_planar: T, twW: Tuple[T, T], twH: Tuple[T, T], mask_logits: T, temp: float, band_scale2: T, out: T,
+              ch_lo: int, ch_hi: int):
+    _chk(x_planar, "fft_bands.x")
+    C, H, W = x_planar.shape
+    nwork = 4 * C * H * (W // 2 + 1)
+    work = torch.empty(nwork, device=x_planar.device, dtype=torch.float32)
+    op, ldo, *_ = _nhwc(out, "fft_bands.out")
+    msz = mask_logits.shape[-1]
+    _lib.check(_L().ff_fft_bands(x_planar.data_ptr(), C, H, W, twW[0].data_ptr(), twW[1].data_ptr(), twH[0].data_ptr(),
+                                 twH[1].data_ptr(), mask_logits.data_ptr(), msz, float(temp), band_scale2.data_ptr(),
+                                 work.data_ptr(), nwork, op, ldo, ch_lo, ch_hi, _stream()))
+
+
+def chan_attn_weights(qkv: T, q_off: int, k_off: int, temperature: T) -> T:
+    qp, ld, rows, C = rows_view(qkv, "chan_attn_weights.qkv")
+    nwork = int(_L().ff_chan_attn_workspace(rows))
+    work = torch.empty(nwork, device=qkv.device, dtype=torch.float32)
+    wbd = torch.empty((180, 180), device=qkv.device, dtype=torch.float32)
+    _lib.check(_L().ff_chan_attn_weights(qp, ld, q_off, k_off, rows, temperature.data_ptr(), wbd.data_ptr(), work.data_ptr(),
+                                         nwork, _stream()))
+    return wbd
+
+
+def band_mha_core(qkv: T, P: int, nbands: int, heads: int) -> T:
+    _chk(qkv, "band_mha_core.qkv")
+    E = qkv.shape[-1] // 3
+    out = torch.empty((P * nbands, E), device=qkv.device, dtype=torch.float32)
+    _lib.check(_L().ff_band_mha_core(qkv.data_ptr(), out.data_ptr(), P, nbands, heads, _stream()))
+    return out
+
+
+def band_weight(x: T, att: T, imp: T) -> T:
+    out = torch.empty_like(x)
+    P = x.numel() // x.shape[-1]
+    _lib.check(_L().ff_band_weight(x.data_ptr(), att.data_ptr(), imp.data_ptr(), out.data_ptr(), P, x.shape[-1] // 3, _stream()))
+    return out
+
+
+def freq_guidance(b3: T) -> T:
+    P = b3.numel() // 9
+    out = torch.empty(tuple(b3.shape[:-1]) + (3,), device=b3.device, dtype=torch.float32)
+    _lib.check(_L().ff_freq_guidance(b3.data_ptr(), out.data_ptr(), P, _stream()))
+    return out
+
+
+def dynamic_gates(graw: T, dif: T) -> T:
+    P = graw.numel() // 3
+    out = torch.empty_like(graw)
+    _lib.check(_L().ff_dynamic_gates(graw.data_ptr(), dif.data_ptr(), out.data_ptr(), P, _stream()))
+    return out
+
+
+def fuse_blend(experts9: T, hier3: T, guide3: T, gates3: T, dif1: T) -> T:
+    _, Hh, Wh, _ = experts9.shape
+    _, Hl, Wl, _ = guide3.shape
+    out = torch.empty((1, Hh, Wh, 3), device=experts9.device, dtype=torch.float32)
+    _lib.check(_L().ff_fuse_blend(experts9.data_ptr(), hier3.data_ptr(), guide3.data_ptr(), gates3.data_ptr(), dif1.data_ptr(),
+                                  out.data_ptr(), Hh, Wh, Hl, Wl, _stream()))
+    return out

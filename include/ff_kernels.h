@@ -1,0 +1,137 @@
+/* C ABI of libff_hip.so -- the MI355X (gfx950) kernel library behind the FreqFusion x4 inference path.
+ *
+ * Boundary contract.  The reference has no FFI: its "operators" are the ATen ops
+ * PyTorch dispatches from models/team29_FreqFusion/io.py:221 -> src/models/enhanced_fusion.py:694-754.
+ * Each entry point below replaces one cluster of those ATen ops (cited per function); the Python host
+ * (image-super-resolution-2_amd/*.py) binds them with ctypes, exactly as a reference maintainer would
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types.  All tensors are fp32 DEVICE pointers owned by the caller;
+ *     the library allocates nothing and keeps no state (workspaces are passed in).
+ *   - activations are NHWC / token-major: element (b, y, x, c) at ((b*H + y)*W + x)*ld + c.  `ld*`
+ *     arguments are row (pixel) strides in floats, so channel slices of wider tensors are addressed in place.
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); every call is asynchronous
+ *     on it and graph-capturable (no allocation, no synchronisation inside).
+ *   - return 0 on success; otherwise nothing was launched and ff_last_error() describes why.
+ */
+#ifndef FF_KERNELS_H
+#define FF_KERNELS_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FF_ACT_NONE 0
+#define FF_ACT_GELU 1    /* exact erf GELU (nn.GELU default) */
+#define FF_ACT_RELU 2
+#define FF_ACT_LRELU 3   /* negative slope 0.01 (nn.LeakyReLU default) */
+#define FF_ACT_SIGMOID 4
+
+const char* ff_last_error(void);
+int ff_abi_version(void);
+int ff_device_cu_count(void);
+
+/* Implicit-GEMM convolution / GEMM on fp32 MFMA:
+ *   out[m][n] = res[m][n] + alpha * mul[n] * act( sum_k A[m][k] * w[n][k] + bias[n] )
+ * A gathered from in[B][H][W][ldi] (channels [0,Cin), zero padding); w is [Cout][KH*KW*Cin] with
+ * k = (ky*KW + kx)*Cin + ci.  bias / mul / res may be NULL.  shuffle = 2 folds nn.PixelShuffle(2) into the
+ * store (out/res are then [B][2Ho][2Wo][ld] with Cout/4 channels).  A GEMM on rows [M][K] is
+ * B=1,H=1,W=M,KH=KW=1.  tile_hint 0 = auto.
+ * Replaces nn.Linear / nn.Conv2d (+bias +GELU/ReLU/LeakyReLU/Sigmoid +residual +PixelShuffle):
+ * hat_arch.py:67-69,83-94,172,194,608,699-700,859; dat_arch.py:163-168,501,559,792,964;
+ * nafnet_arch.py:77,82,95,96,160,162,174,184-185; hierarchical_fusion.py:96-127; enhanced_fusion.py:266-290;
+ * edge_enhancement.py:100-180; fusion_network.py:179-197,553-576; large_kernel_attention.py:75,131-135,191-205. */
+int ff_conv2d(const float* in, const float* w, const float* bias, const float* mul, const float* res, float* out,
+              int B, int H, int W, int Cin, int ldi, int Ho, int Wo, int Cout, int ldo, int ldr, int KH, int KW,
+              int sy, int sx, int py, int px, int act, float alpha, int shuffle, int tile_hint, void* stream);
+
+/* Fused window attention softmax((q*scale) k^T + bias (+mask)) v on fp32 MFMA; one workgroup per
+ * (window, head).  qkv is the token tensor [B][H][W][ldq]; q/k/v of head h live at *_off + h*d.
+ * Queries: wh x ww windows (wh*ww == 256) on the (Hp, Wp) zero-padded grid, cyclically shifted by
+ * (shift_h, shift_w); keys: kh x kw window centred on the query window (zero outside the image).
+ * biasT is [heads][kh*kw][256] (key-major).  use_mask adds the -100 shifted-window region mask.
+ * Output written un-shifted and cropped at out[token][o_off + h*d ..].
+ * Replaces hat_arch.py:97-126,165-196,280-303 (+mask :921-940), :400-433 (OCAB unfold path),
+ * dat_arch.py:62-96,269-342,505-548. */
+int ff_window_attn(const float* qkv, int ldq, int q_off, int k_off, int v_off, float* out, int ldo, int o_off,
+                   const float* biasT, int B, int H, int W, int Hp, int Wp, int wh, int ww, int kh, int kw,
+                   int shift_h, int shift_w, int use_mask, int heads, int d, float scale, void* stream);
+
+/* LayerNorm over the last axis of [rows][C] (nn.LayerNorm and NAFNet LayerNorm2d in NHWC):
+ * hat_arch.py:272,307,397,437,964; dat_arch.py:117,734-735,931,1003; nafnet_arch.py:35-41. */
+int ff_layernorm(const float* in, int ldi, float* out, int ldo, long long rows, int C, const float* gamma,
+                 const float* beta, float eps, void* stream);
+
+/* Global average pool over the P pixels of each of B images: out[B][C] (AdaptiveAvgPool2d(1):
+ * hat_arch.py:50; dat_arch.py:411,603; nafnet_arch.py:86).  work: ff_pool_mean_workspace floats. */
+int ff_pool_mean(const float* in, int ld, int B, long long P, int C, float* out, float* work, long long work_floats,
+                 void* stream);
+long long ff_pool_mean_workspace(int B, long long P, int C);
+
+/* out[b] = act2(W2 . act1(W1 . in[b] + b1) + b2) * post; W2 == NULL -> single layer act1(W1.in+b1)*post.
+ * The 1x1-conv MLPs that follow the pools (hat_arch.py:51-54; dat_arch.py:412-416,604-608; nafnet_arch.py:87). */
+int ff_vec_mlp(const float* in, int B, int Cin, const float* W1, const float* b1, int Ch, int act1, const float* W2,
+               const float* b2, int Cout, int act2, float post, float* out, void* stream);
+
+/* Depth-wise conv, NHWC, zero padding, weights tap-major [KH*KW][C]:
+ *   out = act((sum w*x + bias) * post_scale + post_shift)
+ * dat_arch.py:109,403-407; nafnet_arch.py:78-81; large_kernel_attention.py:59-73; edge_enhancement.py:62. */
+int ff_dwconv2d(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int Ho, int Wo,
+                const float* w_tapmajor, const float* bias, int KH, int KW, int sy, int sx, int py, int px,
+                const float* post_scale, const float* post_shift, int act, void* stream);
+
+/* out = ka*a*ca[c]*pa[p] + kb*b*cb[c]*pb[p]   (b, ca, cb, pa, pb may be NULL; clamp01 clamps to [0,1]) */
+int ff_mix2(float* out, int ldo, const float* a, int lda, const float* b, int ldb, long long rows, int C, float ka,
+            float kb, const float* ca, const float* cb, const float* pa, int ldpa, const float* pb, int ldpb,
+            int clamp01, void* stream);
+/* out = a + alpha*b*c   (a may be NULL) */
+int ff_fma3(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c, int ldc,
+            long long rows, int C, float alpha, void* stream);
+/* out = act(in*scale[c] + shift[c])   (eval BatchNorm ahead of zero-padded convs) */
+int ff_affine(float* out, int ldo, const float* in, int ldi, long long rows, int C, const float* scale,
+              const float* shift, int act, void* stream);
+
+/* NCHW image -> NHWC (+add[c]), padded to (Hp, Wp) with zeros (0) or reflection (1)
+ * (expert_loader.py:63-96; nafnet_arch.py:220-225), and back (+add[c], crop, optional clamp to [0,1]). */
+int ff_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Hp, int Wp, int ldo,
+                    const float* add, int pad_mode, void* stream);
+int ff_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, int Hs, int Ws, int ldi,
+                    const float* add, int clamp01, void* stream);
+
+/* Bilinear (mode 0) / bicubic A=-0.75 (mode 1) resize, align_corners=False, generic element strides.
+ * scale_* = source step per destination pixel exactly as ATen computes it. */
+int ff_resize(const float* in, long long isb, long long isc, long long isy, long long isx, int Hi, int Wi, float* out,
+              long long osb, long long osc, long long osy, long long osx, int Ho, int Wo, int B, int C, float scale_h,
+              float scale_w, int mode, float mul, void* stream);
+int ff_avgpool2(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, void* stream);
+
+/* Frequency bands of the planar LR image x[C][H][W] written into out[H][W][ldo] channel groups.
+ * multi_domain_frequency.py:146-196 (DCT), :273-299 (DWT pass), :352-385 (FFT low/high). */
+int ff_dct8_bands(const float* x, int C, int H, int W, const float* dct_mat, const float* masks3,
+                  const float* band_scale, float* out, int ldo, int ch_off, void* stream);
+int ff_dwt_pass(const float* in, int C, int H, int W, int axis, const float* lo8, const float* hi8, float* out_lo,
+                float* out_hi, void* stream);
+int ff_fft_bands(const float* x, int C, int H, int W, const float* twW_cos, const float* twW_sin,
+                 const float* twH_cos, const float* twH_sin, const float* mask_logits, int msz, float temp,
+                 const float* band_scale2, float* work, long long work_floats, float* out, int ldo, int ch_lo,
+                 int ch_hi, void* stream);
+
+/* DAT channel attention (dat_arch.py:627-647): token-axis L2 norms + per-head 30x30 gram + softmax ->
+ * block-diagonal [180][180] matrix (apply with ff_conv2d on v).  work: ff_chan_attn_workspace floats. */
+int ff_chan_attn_weights(const float* qkv, int ld, int q_off, int k_off, long long N, const float* temperature,
+                         float* wbd, float* work, long long work_floats, void* stream);
+long long ff_chan_attn_workspace(long long N);
+
+/* Fusion-stack pointwise kernels (see csrc/fusion_ops.hip for the reference lines). */
+int ff_band_mha_core(const float* qkv, float* out, long long P, int nbands, int heads, void* stream);
+int ff_band_weight(const float* x, const float* att, const float* imp, float* out, long long P, int nbands,
+                   void* stream);
+int ff_freq_guidance(const float* bands3, float* guide, long long P, void* stream);
+int ff_dynamic_gates(const float* graw, const float* dif, float* gates, long long P, void* stream);
+int ff_fuse_blend(const float* experts9, const float* hier3, const float* guide3, const float* gates3,
+                  const float* dif1, float* out3, int Hh, int Wh, int Hl, int Wl, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

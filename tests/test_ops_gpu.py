@@ -1,0 +1,340 @@
+"""GPU parity of every C-ABI kernel against plain PyTorch fp32 ops (run with -m gpu on the MI355X box).
+Tolerances: fp32 MFMA is an exact-fp32 fma chain, so contractions agree with torch to ~1e-5 relative of
+the accumulated magnitude; pointwise ops to a few ulp."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from isr2_amd import lib
+    lib.load()
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, dev, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def close(a, b, tol, name=""):
+    err = (a - b).abs().max().item()
+    ref = max(1.0, b.abs().max().item())
+    assert err <= tol * ref, f"{name}: max|d|={err:.3e} ref={ref:.3e}"
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p,act", [
+    (1, 16, 16, 180, 180, 3, 1, 1, None),      # RHAG conv
+    (1, 19, 23, 180, 60, 3, 1, 1, "gelu"),     # CAB conv1, ragged M
+    (1, 16, 16, 60, 180, 3, 1, 1, None),
+    (2, 12, 20, 3, 64, 3, 1, 1, "relu"),       # scalar path (Cin=3)
+    (1, 16, 16, 73, 64, 3, 1, 1, "gelu"),      # scalar path (Cin=73)
+    (1, 32, 32, 64, 128, 2, 2, 0, None),       # NAFNet down
+    (1, 16, 16, 64, 3, 3, 1, 1, "sigmoid"),    # tiny Cout
+    (1, 8, 8, 1024, 2048, 1, 1, 0, None),      # 128x128 tile config
+    (1, 24, 24, 32, 1, 3, 1, 1, "sigmoid"),
+])
+def test_conv2d_matches_torch(dev, B, H, W, Cin, Cout, k, s, p, act):
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_conv
+    x = rnd(B, Cin, H, W, dev=dev, seed=1)
+    w = rnd(Cout, Cin, k, k, dev=dev, seed=2, scale=1.0 / math.sqrt(Cin * k * k))
+    b = rnd(Cout, dev=dev, seed=3, scale=0.1)
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    ref = {"gelu": F.gelu, "relu": F.relu, "sigmoid": torch.sigmoid, None: lambda t: t}[act](ref)
+    out = ops.conv2d(x.permute(0, 2, 3, 1).contiguous(), pack_conv(w), b, ksize=(k, k), stride=(s, s), pad=(p, p), act=act)
+    close(out.permute(0, 3, 1, 2), ref, 2e-5, "conv2d")
+
+
+def test_conv2d_epilogue_residual_mul_alpha_and_slices(dev):
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_conv
+    B, H, W, Cin, Cout = 1, 20, 20, 64, 64
+    wide = rnd(B, H, W, 100, dev=dev, seed=4)                 # input is a channel slice [10:74] of a wider buffer
+    x = wide[..., 10:74]
+    w = rnd(Cout, Cin, 1, 1, dev=dev, seed=5, scale=0.1)
+    b = rnd(Cout, dev=dev, seed=6, scale=0.1)
+    mul = rnd(Cout, dev=dev, seed=7)
+    res = rnd(B, H, W, Cout, dev=dev, seed=8)
+    obuf = torch.zeros(B, H, W, 96, device=dev)
+    out = ops.conv2d(x, pack_conv(w), b, act="lrelu", res=res, mul=mul, alpha=0.3, out=obuf[..., 16:80])
+    ref = res + 0.3 * mul * F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2), w, b), 0.01).permute(0, 2, 3, 1)
+    close(out, ref, 2e-5, "epilogue")
+    assert obuf[..., :16].abs().max() == 0 and obuf[..., 80:].abs().max() == 0
+
+
+def test_conv2d_pixel_shuffle(dev):
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_conv
+    x = rnd(1, 64, 12, 14, dev=dev, seed=9)
+    w = rnd(256, 64, 3, 3, dev=dev, seed=10, scale=0.05)
+    b = rnd(256, dev=dev, seed=11, scale=0.1)
+    ref = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2)
+    out = ops.conv2d(x.permute(0, 2, 3, 1).contiguous(), pack_conv(w), b, ksize=(3, 3), pad=(1, 1), shuffle=2)
+    close(out.permute(0, 3, 1, 2), ref, 2e-5, "shuffle")
+
+
+def test_linear_matches_torch(dev):
+    from isr2_amd import ops
+    x = rnd(1000, 180, dev=dev, seed=12)
+    w = rnd(540, 180, dev=dev, seed=13, scale=0.07)
+    b = rnd(540, dev=dev, seed=14, scale=0.1)
+    close(ops.linear(x, w, b), F.linear(x, w, b), 2e-5, "linear")
+    close(ops.linear(x, w, b, act="gelu"), F.gelu(F.linear(x, w, b)), 2e-5, "linear+gelu")
+
+
+@pytest.mark.parametrize("C,eps", [(180, 1e-5), (64, 1e-6), (360, 1e-5), (1024, 1e-6), (128, 1e-6)])
+def test_layernorm(dev, C, eps):
+    from isr2_amd import ops
+    x = rnd(777, C, dev=dev, seed=15, scale=2.0) + 0.5
+    g = rnd(C, dev=dev, seed=16) * 0.1 + 1
+    b = rnd(C, dev=dev, seed=17) * 0.1
+    close(ops.layernorm(x, g, b, eps), F.layer_norm(x, (C,), g, b, eps), 1e-5, "ln")
+
+
+def test_layernorm_slice(dev):
+    from isr2_amd import ops
+    y = rnd(500, 720, dev=dev, seed=18)
+    g = rnd(360, dev=dev, seed=19) * 0.1 + 1
+    b = rnd(360, dev=dev, seed=20) * 0.1
+    close(ops.layernorm(y[:, 360:], g, b), F.layer_norm(y[:, 360:], (360,), g, b), 1e-5, "ln slice")
+
+
+def _hat_bias(table, ws, ows, heads):
+    from oracle import freqfusion_oracle as O
+    rpi = O.hat_rel_index_sa(ws) if ows == ws else O.hat_rel_index_oca(ws, ows)
+    return table[rpi.reshape(-1).to(table.device)].reshape(ws * ws, ows * ows, heads).permute(2, 0, 1).contiguous()
+
+
+@pytest.mark.parametrize("H,W,shift", [(32, 48, 0), (32, 48, 8), (16, 16, 8)])
+def test_window_attn_hat(dev, H, W, shift):
+    """W-MSA / SW-MSA against the oracle's window attention math evaluated with torch on the GPU."""
+    from isr2_amd import ops
+    from oracle import freqfusion_oracle as O
+    heads, d, ws, C = 6, 30, 16, 180
+    qkv = rnd(1, H, W, 3 * C, dev=dev, seed=21)
+    table = rnd((2 * ws - 1) ** 2, heads, dev=dev, seed=22, scale=0.5)
+    bias = _hat_bias(table, ws, ws, heads)                          # (heads, nq, nk)
+    out = torch.zeros(1, H, W, C, device=dev)
+    ops.window_attn(qkv, out, bias.transpose(1, 2).contiguous(), q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W,
+                    win=(ws, ws), kwin=(ws, ws), shift=(shift, shift), use_mask=shift > 0, heads=heads, d=d, scale=d ** -0.5)
+    xi = qkv
+    if shift:
+        xi = torch.roll(xi, shifts=(-shift, -shift), dims=(1, 2))
+    xw = O._win_split(xi, ws, ws).reshape(-1, ws * ws, 3, heads, d).permute(2, 0, 3, 1, 4)
+    mask = O._region_mask(H, W, ws, ws, ws // 2, ws // 2).to(dev) if shift else None
+    o = O._softmax_attn(xw[0] * d ** -0.5, xw[1], xw[2], bias, mask).transpose(1, 2).reshape(-1, ws * ws, C)
+    o = O._win_merge(o, ws, ws, H, W)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    close(out, o, 2e-5, "window_attn")
+
+
+def test_window_attn_ocab(dev):
+    from isr2_amd import ops
+    from oracle import freqfusion_oracle as O
+    heads, d, ws, ows, C, H, W = 6, 30, 16, 24, 180, 32, 32
+    qkv = rnd(1, H, W, 3 * C, dev=dev, seed=23)
+    table = rnd((ws + ows - 1) ** 2, heads, dev=dev, seed=24, scale=0.5)
+    bias = _hat_bias(table, ws, ows, heads)
+    out = torch.zeros(1, H, W, C, device=dev)
+    ops.window_attn(qkv, out, bias.transpose(1, 2).contiguous(), q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W,
+                    win=(ws, ws), kwin=(ows, ows), shift=(0, 0), use_mask=False, heads=heads, d=d, scale=d ** -0.5)
+    q = O._win_split(qkv[..., :C], ws, ws)
+    kv = qkv[..., C:].permute(0, 3, 1, 2)
+    nwin = (H // ws) * (W // ws)
+    kvw = F.unfold(kv, kernel_size=ows, stride=ws, padding=(ows - ws) // 2)
+    kvw = kvw.reshape(1, 2, C, ows * ows, nwin).permute(1, 0, 4, 3, 2).reshape(2, nwin, ows * ows, C)
+    qh = q.reshape(-1, ws * ws, heads, d).transpose(1, 2) * d ** -0.5
+    kh = kvw[0].reshape(-1, ows * ows, heads, d).transpose(1, 2)
+    vh = kvw[1].reshape(-1, ows * ows, heads, d).transpose(1, 2)
+    o = O._softmax_attn(qh, kh, vh, bias, None).transpose(1, 2).reshape(-1, ws * ws, C)
+    close(out, O._win_merge(o, ws, ws, H, W), 2e-5, "ocab")
+
+
+@pytest.mark.parametrize("H,W,shifted", [(32, 64, False), (48, 48, True), (64, 32, True)])
+def test_window_attn_dat_branches(dev, H, W, shifted):
+    """DAT 8x32 / 32x8 branches on channel halves, zero tokens beyond (H, W), optional shift + mask."""
+    from isr2_amd import ops
+    from oracle import freqfusion_oracle as O
+    C, half, hh, d = 180, 90, 3, 30
+    m = 32
+    Hp, Wp = H + (m - H % m) % m, W + (m - W % m) % m
+    qkv = rnd(1, H, W, 3 * C, dev=dev, seed=25)
+    out = torch.zeros(1, H, W, C, device=dev)
+    qkv5 = F.pad(qkv.reshape(1, H, W, 3, C), (0, 0, 0, 0, 0, Wp - W, 0, Hp - H))
+    for br in range(2):
+        wh, ww = (8, 32) if br == 0 else (32, 8)
+        sh, sw = wh // 2, ww // 2
+        bias = rnd(hh, 256, 256, dev=dev, seed=26 + br, scale=0.5)
+        ops.window_attn(qkv, out, bias.transpose(1, 2).contiguous(), q_off=br * half, k_off=C + br * half,
+                        v_off=2 * C + br * half, o_off=br * half, H=H, W=W, Hp=Hp, Wp=Wp, win=(wh, ww), kwin=(wh, ww),
+                        shift=(sh, sw) if shifted else (0, 0), use_mask=shifted, heads=hh, d=d, scale=d ** -0.5)
+        t = qkv5[..., br * half:(br + 1) * half]
+        if shifted:
+            t = torch.roll(t, shifts=(-sh, -sw), dims=(1, 2))
+        tw = [O._win_split(t[:, :, :, i], wh, ww).reshape(-1, wh * ww, hh, d).transpose(1, 2) for i in range(3)]
+        mask = O._region_mask(Hp, Wp, wh, ww, sh, sw).to(dev) if shifted else None
+        o = O._softmax_attn(tw[0] * d ** -0.5, tw[1], tw[2], bias, mask).transpose(1, 2).reshape(-1, wh * ww, half)
+        o = O._win_merge(o, wh, ww, Hp, Wp)
+        if shifted:
+            o = torch.roll(o, shifts=(sh, sw), dims=(1, 2))
+        close(out[..., br * half:(br + 1) * half], o[:, :H, :W], 2e-5, f"dat branch {br}")
+
+
+def test_pool_and_vec_mlp(dev):
+    from isr2_amd import ops
+    x = rnd(2, 37, 41, 180, dev=dev, seed=30)
+    pm = ops.pool_mean(x)
+    close(pm, x.mean(dim=(1, 2)), 1e-5, "pool")
+    W1, b1 = rnd(6, 180, dev=dev, seed=31, scale=0.1), rnd(6, dev=dev, seed=32, scale=0.1)
+    W2, b2 = rnd(180, 6, dev=dev, seed=33, scale=0.3), rnd(180, dev=dev, seed=34, scale=0.1)
+    out = ops.vec_mlp(pm, W1, b1, "relu", W2, b2, "sigmoid", post=0.01)
+    ref = torch.sigmoid(F.linear(F.relu(F.linear(pm, W1, b1)), W2, b2)) * 0.01
+    close(out, ref, 1e-5, "vec_mlp2")
+    Wb, bb = rnd(1024, 1024, dev=dev, seed=35, scale=0.03), rnd(1024, dev=dev, seed=36, scale=0.1)
+    v = rnd(1, 1024, dev=dev, seed=37)
+    close(ops.vec_mlp(v, Wb, bb, None), F.linear(v, Wb, bb), 1e-5, "vec_mlp1")
+
+
+@pytest.mark.parametrize("C,kh,kw,sy,sx", [(180, 3, 3, 1, 1), (64, 5, 5, 1, 1), (64, 1, 21, 1, 1), (64, 21, 1, 1, 1),
+                                           (3, 5, 5, 1, 1), (576, 3, 3, 1, 1)])
+def test_dwconv(dev, C, kh, kw, sy, sx):
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_dw
+    x = rnd(1, C, 33, 29, dev=dev, seed=40)
+    w = rnd(C, 1, kh, kw, dev=dev, seed=41, scale=0.3)
+    b = rnd(C, dev=dev, seed=42, scale=0.1)
+    ps, pt = rnd(C, dev=dev, seed=43) * 0.1 + 1, rnd(C, dev=dev, seed=44) * 0.1
+    ref = F.gelu(F.conv2d(x, w, b, stride=(sy, sx), padding=(kh // 2, kw // 2), groups=C) * ps[None, :, None, None] + pt[None, :, None, None])
+    out = ops.dwconv2d(x.permute(0, 2, 3, 1).contiguous(), pack_dw(w), b, ksize=(kh, kw), stride=(sy, sx), pad=(kh // 2, kw // 2),
+                       post_scale=ps, post_shift=pt, act="gelu")
+    close(out.permute(0, 3, 1, 2), ref, 1e-5, "dwconv")
+
+
+def test_pointwise(dev):
+    from isr2_amd import ops
+    a, b = rnd(300, 64, dev=dev, seed=50), rnd(300, 64, dev=dev, seed=51)
+    ca, cb = rnd(64, dev=dev, seed=52), rnd(64, dev=dev, seed=53)
+    pa, pb = rnd(300, 1, dev=dev, seed=54), rnd(300, 1, dev=dev, seed=55)
+    close(ops.mix2(a, b, ka=0.7, kb=0.3, ca=ca, cb=cb, pa=pa, pb=pb), 0.7 * a * ca * pa + 0.3 * b * cb * pb, 1e-6, "mix2")
+    close(ops.mix2(a, clamp01=True), a.clamp(0, 1), 0, "clamp")
+    y = rnd(300, 128, dev=dev, seed=56)
+    close(ops.fma3(None, y[:, :64], y[:, 64:]), y[:, :64] * y[:, 64:], 1e-6, "gate")
+    close(ops.fma3(a, b, y[:, 64:], 0.1), a + 0.1 * b * y[:, 64:], 1e-6, "fma3")
+    close(ops.affine(a, ca, cb, "gelu"), F.gelu(a * ca + cb), 1e-6, "affine")
+
+
+def test_layout_roundtrip_and_reflect(dev):
+    from isr2_amd import ops
+    x = rnd(1, 3, 42, 52, dev=dev, seed=60)
+    add = torch.tensor([-0.4488, -0.4371, -0.4040], device=dev)
+    y = ops.nchw_to_nhwc(x, 48, 64, add=add, pad_mode="reflect")
+    ref = F.pad(x + add[None, :, None, None], (0, 12, 0, 6), mode="reflect").permute(0, 2, 3, 1)
+    close(y, ref, 1e-7, "reflect")
+    z = ops.nchw_to_nhwc(x, 48, 64)
+    close(z, F.pad(x, (0, 12, 0, 6)).permute(0, 2, 3, 1), 0, "zero pad")
+    back = ops.nhwc_to_nchw(y, 42, 52, add=-add, clamp01=True)
+    close(back, x.clamp(0, 1), 1e-6, "roundtrip")
+
+
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo,sf", [(16, 20, 64, 80, None), (64, 80, 16, 20, None), (21, 26, 10, 13, 0.5),
+                                            (42, 52, 10, 13, 0.25), (33, 33, 256, 129, None), (40, 40, 40, 40, None)])
+def test_bilinear(dev, Hi, Wi, Ho, Wo, sf):
+    from isr2_amd import ops
+    x = rnd(1, 5, Hi, Wi, dev=dev, seed=61)
+    if sf is None:
+        ref = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False)
+    else:
+        ref = F.interpolate(x, scale_factor=sf, mode="bilinear", align_corners=False)
+        assert ref.shape[-2:] == (Ho, Wo)
+    out = ops.resize(x.permute(0, 2, 3, 1).contiguous(), (Ho, Wo), scale_factor=sf)
+    close(out.permute(0, 3, 1, 2), ref, 2e-6, "bilinear nhwc")
+    out2 = ops.resize(x, (Ho, Wo), scale_factor=sf, layout="nchw")
+    close(out2.permute(0, 3, 1, 2), ref, 2e-6, "bilinear planar")
+
+
+def test_bicubic_x4_and_avgpool(dev):
+    from isr2_amd import ops
+    x = rnd(1, 3, 23, 31, dev=dev, seed=62).clamp(-1, 1) * 0.5 + 0.5
+    ref = F.interpolate(x, scale_factor=4, mode="bicubic", align_corners=False)
+    out = ops.resize(x, (92, 124), mode="bicubic", scale_factor=4, layout="nchw")
+    close(out.permute(0, 3, 1, 2), ref, 3e-6, "bicubic")
+    y = rnd(1, 3, 31, 30, dev=dev, seed=63)
+    close(ops.avgpool2(y.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2), F.avg_pool2d(y, 2, 2), 1e-6, "avgpool")
+
+
+@pytest.mark.parametrize("H,W", [(48, 48), (42, 52), (64, 37)])
+def test_freq_bands(dev, H, W):
+    """DCT / DWT / FFT bands against the CPU oracle (which is pinned to the reference)."""
+    from isr2_amd import ops
+    from isr2_amd.fusion import FreqBands
+    from isr2_amd.weights import synth_state_dict
+    from oracle import freqfusion_oracle as O
+    sd = synth_state_dict(1234, parts=("fusion",))
+    lr = torch.from_numpy(np.random.default_rng(3).random((1, 3, H, W), dtype=np.float32))
+    ref = torch.cat(O.freq_decompose(sd, lr), dim=1).permute(0, 2, 3, 1)
+    fb = FreqBands({k: v.to(dev) for k, v in sd.items()}, dev)
+    out = fb(lr.to(dev))
+    for i in range(9):
+        close(out[..., 3 * i:3 * i + 3].cpu(), ref[..., 3 * i:3 * i + 3], 1e-5, f"band {i}")
+
+
+def test_chan_attn_weights(dev):
+    from isr2_amd import ops
+    N, C, heads, d = 3000, 180, 6, 30
+    qkv = rnd(N, 3 * C, dev=dev, seed=70)
+    temp = (rnd(heads, dev=dev, seed=71) * 0.2 + 1.0).contiguous()
+    wbd = ops.chan_attn_weights(qkv, 0, C, temp)
+    q = qkv[:, :C].reshape(N, heads, d).permute(1, 2, 0)
+    k = qkv[:, C:2 * C].reshape(N, heads, d).permute(1, 2, 0)
+    a = torch.softmax((F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)) * temp[:, None, None], dim=-1)
+    ref = torch.block_diag(*[a[h] for h in range(heads)])
+    close(wbd, ref, 1e-5, "chan attn")
+
+
+def test_band_mha_and_fusion_pointwise(dev):
+    from isr2_amd import ops
+    P, nb, heads, E = 500, 9, 4, 64
+    qkv = rnd(P * nb, 3 * E, dev=dev, seed=72)
+    out = ops.band_mha_core(qkv, P, nb, heads)
+    q, k, v = [t.reshape(P, nb, heads, 16).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+    ref = (torch.softmax((q * 0.25) @ k.transpose(-2, -1), dim=-1) @ v).transpose(1, 2).reshape(P * nb, E)
+    close(out, ref, 1e-5, "band mha")
+    x, att, imp = rnd(P, 27, dev=dev, seed=73), rnd(P, 9, dev=dev, seed=74), rnd(9, dev=dev, seed=75)
+    close(ops.band_weight(x, att, imp), (x.reshape(P, 9, 3) * att[:, :, None] * imp[None, :, None]).reshape(P, 27), 1e-6, "band weight")
+    b3 = rnd(1, 20, 25, 9, dev=dev, seed=76)
+    m = b3.reshape(1, 20, 25, 3, 3).abs().mean(-1)
+    tot = m.sum(-1, keepdim=True) + 1e-8
+    close(ops.freq_guidance(b3), torch.stack([m[..., 2], m[..., 1], m[..., 0]], -1) / tot, 1e-6, "guidance")
+
+
+def test_fuse_blend(dev):
+    from isr2_amd import ops
+    Hl, Wl = 12, 15
+    Hh, Wh = 4 * Hl, 4 * Wl
+    E = rnd(1, Hh, Wh, 9, dev=dev, seed=80).abs()
+    hier = rnd(1, Hh, Wh, 3, dev=dev, seed=81).abs()
+    guide = torch.softmax(rnd(1, Hl, Wl, 3, dev=dev, seed=82), -1)
+    gates = torch.sigmoid(rnd(1, Hl, Wl, 3, dev=dev, seed=83))
+    dif = torch.sigmoid(rnd(1, Hl, Wl, 1, dev=dev, seed=84))
+    out = ops.fuse_blend(E, hier, guide, gates, dif)
+
+    def up(t):
+        return F.interpolate(t.permute(0, 3, 1, 2), size=(Hh, Wh), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+
+    g, gt, df = up(guide), up(gates), up(dif)
+    ex = [E[..., 0:3], E[..., 3:6], E[..., 6:9]]
+    f0 = hier * 0.7 + 0.3 * sum(e * g[..., i:i + 1] for i, e in enumerate(ex))
+    dyn = sum(e * gt[..., i:i + 1] for i, e in enumerate(ex)) / (gt.sum(-1, keepdim=True) + 1e-8)
+    close(out, f0 * (1 - 0.3 * df) + dyn * (0.3 * df), 2e-6, "fuse blend")
