@@ -155,3 +155,48 @@ extern "C" int ff_nhwc_to_nchw(const float* in, float* out, int B, int C, int H,
   FF_LAUNCH_CHECK("ff_nhwc_to_nchw");
   return FF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Overlap-tile blending (models/team29_FreqFusion/io.py:104-121): acc[c][sy+y][sx+x] += tile[c][y][x]*wy[y]*wx[x],
+// wsum[sy+y][sx+x] += wy[y]*wx[x]; then acc /= max(wsum, 1e-8).  Planar (NCHW) like the plugin's output.
+__global__ __launch_bounds__(256) void tile_accum_kernel(const float* __restrict__ tile, int C, int th, int tw,
+                                                         const float* __restrict__ wy, const float* __restrict__ wx,
+                                                         float* __restrict__ acc, float* __restrict__ wsum, int H, int W, int sy,
+                                                         int sx) {
+  const long long total = (long long)th * tw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % tw), y = (int)(i / tw);
+    const float wgt = wy[y] * wx[x];
+    const long long o = (long long)(sy + y) * W + sx + x;
+    for (int c = 0; c < C; ++c) acc[(long long)c * H * W + o] += tile[((long long)c * th + y) * tw + x] * wgt;
+    wsum[o] += wgt;
+  }
+}
+
+__global__ __launch_bounds__(256) void tile_normalize_kernel(float* __restrict__ acc, const float* __restrict__ wsum, int C,
+                                                             long long P) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P * C; i += (long long)gridDim.x * 256)
+    acc[i] = acc[i] / fmaxf(wsum[i % P], 1e-8f);
+}
+
+extern "C" int ff_tile_accum(const float* tile, int C, int th, int tw, const float* wy, const float* wx, float* acc,
+                             float* wsum, int H, int W, int sy, int sx, void* stream) {
+  FF_CHECK_ARG(tile && wy && wx && acc && wsum && C > 0 && th > 0 && tw > 0, "ff_tile_accum: bad args");
+  FF_CHECK_ARG(sy >= 0 && sx >= 0 && sy + th <= H && sx + tw <= W, "ff_tile_accum: tile outside the canvas");
+  long long nb = ((long long)th * tw + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(tile_accum_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, tile, C, th, tw, wy, wx, acc, wsum,
+                     H, W, sy, sx);
+  FF_LAUNCH_CHECK("ff_tile_accum");
+  return FF_OK;
+}
+
+extern "C" int ff_tile_normalize(float* acc, const float* wsum, int C, int H, int W, void* stream) {
+  FF_CHECK_ARG(acc && wsum && C > 0 && H > 0 && W > 0, "ff_tile_normalize: bad args");
+  const long long P = (long long)H * W;
+  long long nb = (P * C + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(tile_normalize_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, acc, wsum, C, P);
+  FF_LAUNCH_CHECK("ff_tile_normalize");
+  return FF_OK;
+}

@@ -389,3 +389,18 @@ def fuse_blend(experts9: T, hier3: T, guide3: T, gates3: T, dif1: T) -> T:
     _lib.check(_L().ff_fuse_blend(experts9.data_ptr(), hier3.data_ptr(), guide3.data_ptr(), gates3.data_ptr(), dif1.data_ptr(),
                                   out.data_ptr(), Hh, Wh, Hl, Wl, _stream()))
     return out
+
+
+def tile_accum(tile: T, wy: T, wx: T, acc: T, wsum: T, sy: int, sx: int):
+    """acc [1,C,H,W] += tile [1,C,th,tw] * (wy x wx) at (sy, sx); wsum [1,1,H,W] += wy x wx."""
+    for t_, n_ in ((tile, "tile"), (wy, "wy"), (wx, "wx"), (acc, "acc"), (wsum, "wsum")):
+        _chk(t_, "tile_accum." + n_)
+    _, C, th, tw = tile.shape
+    _, _, H, W = acc.shape
+    _lib.check(_L().ff_tile_accum(tile.contiguous().data_ptr(), C, th, tw, wy.data_ptr(), wx.data_ptr(), acc.data_ptr(),
+                                  wsum.data_ptr(), H, W, sy, sx, _stream()))
+
+
+def tile_normalize(acc: T, wsum: T):
+    _, C, H, W = acc.shape
+    _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))

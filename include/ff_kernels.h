@@ -98,6 +98,12 @@ int ff_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int
 int ff_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, int Hs, int Ws, int ldi,
                     const float* add, int clamp01, void* stream);
 
+/* Overlap-tile blending of the plugin's tiled fallback (models/team29_FreqFusion/io.py:104-121), planar NCHW:
+ * acc[c][sy+y][sx+x] += tile[c][y][x]*wy[y]*wx[x]; wsum += wy*wx; then acc /= max(wsum, 1e-8). */
+int ff_tile_accum(const float* tile, int C, int th, int tw, const float* wy, const float* wx, float* acc, float* wsum,
+                  int H, int W, int sy, int sx, void* stream);
+int ff_tile_normalize(float* acc, const float* wsum, int C, int H, int W, void* stream);
+
 /* Bilinear (mode 0) / bicubic A=-0.75 (mode 1) resize, align_corners=False, generic element strides.
  * scale_* = source step per destination pixel exactly as ATen computes it. */
 int ff_resize(const float* in, long long isb, long long isc, long long isy, long long isx, int Hi, int Wi, float* out,
