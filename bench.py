@@ -1,0 +1,236 @@
+"""Headline benchmark: output MPix/s of the FreqFusion x4 full 3-expert forward on 256x256 LR tiles.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One process per GPU.  A step = one pass of the hot path (HAT-L + DAT + NAFNet-SR + fusion stack) over
+one synthetic 256x256 LR tile per GPU (BASELINE.json configs[1]); tiles are independent, so ranks
+shard them with NO data-path collective (weak scaling).  The only collective is the one-off RCCL
+broadcast of the frozen weights from rank 0.  The steady state is replayed from a HIP graph (the
+eager Python launch loop is captured once), inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how roofline / cpu_baseline are defined.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TILE = 256
+FLOP_PER_TILE = 11295.4e9          # algorithmic 2xMAC FLOPs of one 256x256 LR tile [measured on the reference]
+MPIX_PER_TILE = (4 * TILE) ** 2 / 1e6
+PEAK_F32_MATRIX_TF = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+SEED = 1234
+
+
+def make_tile(seed: int, size: int = TILE) -> torch.Tensor:
+    """Natural-statistics synthetic LR tile: 1/f-spectrum noise clipped to [0,1]."""
+    rng = np.random.default_rng(seed)
+    fy = np.fft.fftfreq(size)[:, None]
+    fx = np.fft.fftfreq(size)[None, :]
+    amp = 1.0 / np.maximum(np.sqrt(fy ** 2 + fx ** 2), 1.0 / size)
+    chans = []
+    for _ in range(3):
+        img = np.real(np.fft.ifft2(amp * np.exp(1j * rng.random((size, size)) * 2 * np.pi)))
+        chans.append(np.clip((img - img.mean()) / (img.std() + 1e-8) * 0.2 + 0.5, 0, 1))
+    return torch.from_numpy(np.stack(chans)[None].astype(np.float32))
+
+
+def log(msg: str):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def host_threads() -> int:
+    """CPU share of this process (cgroup/affinity aware), capped at 16 -- the GPU box's per-GPU share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def broadcast_weights(rank: int, world: int, dev):
+    """Rank 0 builds the seeded synthetic state dict; everyone else receives it in ONE RCCL broadcast."""
+    from isr2_amd.weights import param_spec, synth_state_dict
+    spec = param_spec()
+    sizes = [int(np.prod(s)) if len(s) else 1 for _, s, _ in spec]
+    total = sum(sizes)
+    if world == 1:
+        return synth_state_dict(SEED), 0.0
+    import torch.distributed as dist
+    flat = torch.empty(total, device=dev, dtype=torch.float32)
+    if rank == 0:
+        sd = synth_state_dict(SEED)
+        flat.copy_(torch.cat([sd[n].reshape(-1) for n, _, _ in spec]))
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.broadcast(flat, src=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out, off = {}, 0
+    for (n, s, _), k in zip(spec, sizes):
+        out[n] = flat[off:off + k].reshape(s)
+        off += k
+    return out, dt
+
+
+def cpu_baseline(sd, threads: int):
+    """The CPU oracle (a port of the reference's PyTorch eval path, pinned to it by golden fixtures) timed on
+    this host's cores on a bounded sample: one 64x64 LR tile = 1/16 of the 256x256 workload."""
+    from oracle import freqfusion_oracle as O
+    torch.set_num_threads(threads)
+    lr = make_tile(3, 64)
+    cpu_sd = {k: v.detach().cpu() for k, v in sd.items()}
+    t0 = time.perf_counter()
+    O.forward(cpu_sd, lr)
+    dt = time.perf_counter() - t0
+    return {"value": (256 * 256 / 1e6) / dt, "unit": "output MPix/s", "cores": threads, "kind": "port",
+            "sample": "CPU oracle (PyTorch fp32 restatement of the reference eval path) on one 64x64 LR tile -> 256x256, "
+                      f"{dt:.1f} s wall; 1/16 of the GPU workload's tile"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true", help="time the eager Python launch loop instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile", type=int, default=TILE)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from isr2_amd import ops
+    from isr2_amd.model import FreqFusionHIP
+
+    log("generating / broadcasting weights")
+    sd, bcast_s = broadcast_weights(rank, world, dev)
+    model = FreqFusionHIP(sd, dev)
+    log("model ready")
+    tile = args.tile
+    lr = make_tile(100 + rank, tile).to(dev)                # a different resident tile per rank
+    flop_per_tile = FLOP_PER_TILE * (tile / TILE) ** 2
+    mpix_per_tile = (4 * tile) ** 2 / 1e6
+
+    # ---- warm-up (also fills the caching allocator and the twiddle caches), then optional graph capture -------
+    t_e = time.perf_counter()
+    out = model(lr)
+    torch.cuda.synchronize()
+    log(f"first eager forward {time.perf_counter() - t_e:.2f} s")
+    t_e = time.perf_counter()
+    out = model(lr)
+    torch.cuda.synchronize()
+    log(f"second eager forward {time.perf_counter() - t_e:.3f} s")
+    use_graph = not args.no_graph
+    graph = None
+    if use_graph:
+        try:
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                model(lr)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = model(lr)
+            torch.cuda.synchronize()
+            log("graph captured")
+        except Exception as e:                               # capture is an optimisation of the launch path only
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); timing the eager loop", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            model(lr)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- per-kernel-class accounting: one extra eager pass with HIP events around every launch ---------------
+    roof, breakdown = None, None
+    if rank == 0:
+        with ops.profile() as prof:
+            model(lr)
+        agg = {}
+        for name, ms, fl, by in prof.records():
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
+        mf = [agg.get(k, [0, 0.0, 0.0, 0.0]) for k in ("conv2d", "linear")]
+        n_l, ms_l, fl_l = mf[0][0] + mf[1][0], mf[0][1] + mf[1][1], mf[0][2] + mf[1][2]
+        achieved = fl_l / (ms_l * 1e-3) / 1e12 if ms_l > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (ff_conv2d: every Linear / Conv2d of the path)",
+                "achieved": achieved, "peak": PEAK_F32_MATRIX_TF, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TF,
+                "traffic": None, "launches_per_tile": n_l, "avg_launch_us": 1e3 * ms_l / max(n_l, 1),
+                "algorithmic_gflop_per_launch": fl_l / max(n_l, 1) / 1e9,
+                "share_of_tile_time": ms_l / max(sum(a[1] for a in agg.values()), 1e-9)}
+        breakdown = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / max(v[1], 1e-9) / 1e9, 2),
+                         "gbps": round(v[3] / max(v[1], 1e-9) / 1e6, 1)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+
+    if rank == 0:
+        value = world * args.steps * mpix_per_tile / elapsed
+        line = {
+            "metric": "output MPix/s at x4 SR (256->1024)", "value": value, "unit": "output MPix/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"FreqFusion x4 full 3-expert forward (HAT-L + DAT + NAFNet-SR + fusion stack), one "
+                                   f"{tile}x{tile} LR tile -> {4 * tile}x{4 * tile} per step per GPU (BASELINE configs[1]); "
+                                   "seeded synthetic weights (172.3 M params), 1/f-noise tiles",
+                       "tile": tile, "tiles_per_step_per_gpu": 1,
+                       "parallelism": f"tile-sharded x{world}, weights RCCL-broadcast once ({bcast_s * 1e3:.1f} ms), no per-tile collectives",
+                       "launch": "hipGraph replay" if graph is not None else "eager"},
+            "path_tflops": world * args.steps * flop_per_tile / elapsed / 1e12,
+            "roofline": roof, "kernel_breakdown_ms_per_tile": breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle, 64x64 tile)")
+            line["cpu_baseline"] = cpu_baseline(sd, host_threads())
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,54 @@ from . import lib as _lib
 ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2, "lrelu": 3, "sigmoid": 4}
 T = torch.Tensor
 
+# ---- optional per-launch instrumentation (bench.py / profiling only; None in the product path) ----------
+_PROF = None          # list collecting (kernel_class, start_event, end_event, algorithmic_flops, algorithmic_bytes)
+_META = [0.0, 0.0]    # [flops, bytes] noted by the wrapper currently running
+
+
+def _note(flops: float = 0.0, nbytes: float = 0.0):
+    _META[0] += flops
+    _META[1] += nbytes
+
+
+def _numel(*ts) -> float:
+    return float(sum(t.numel() for t in ts if t is not None))
+
+
+def _instrument(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        if _PROF is None:
+            return fn(*a, **k)
+        _META[0] = _META[1] = 0.0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        _PROF.append((fn.__name__, e0, e1, _META[0], _META[1]))
+        return r
+    return wrapped
+
+
+class profile:
+    """with ops.profile() as p: ...  -> p.records() = [(kernel_class, ms, flops, bytes)] (events on the current stream)."""
+
+    def __enter__(self):
+        global _PROF
+        self._rec = []
+        _PROF = self._rec
+        return self
+
+    def __exit__(self, *exc):
+        global _PROF
+        _PROF = None
+        torch.cuda.synchronize()
+
+    def records(self):
+        return [(n, e0.elapsed_time(e1), f, b) for n, e0, e1, f, b in self._rec]
+
 
 def _L():
     return _lib.load()
@@ -89,6 +137,7 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
     _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, B, H, W, Cin, ldi, Ho, Wo, Cout, ldo, ldr,
                               KH, KW, stride[0], stride[1], pad[0], pad[1], ACT[act], float(alpha), shuffle, tile_hint,
                               _stream()))
+    _note(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, 4.0 * (_numel(x, w, out, res)))
     return out
 
 
@@ -112,6 +161,7 @@ def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] =
             raise _lib.FFError("linear: res shape mismatch")
     _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, 1, 1, rows, K, ldi, 1, rows, N, ldo, ldr,
                               1, 1, 1, 1, 0, 0, ACT[act], float(alpha), 0, 0, _stream()))
+    _note(2.0 * rows * N * K, 4.0 * (rows * K + N * K + rows * N * (2 if res is not None else 1)))
     return out
 
 
@@ -131,6 +181,8 @@ def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int,
     _lib.check(_L().ff_window_attn(qp, ldq, q_off, k_off, v_off, op, ldo, o_off, biasT.data_ptr(), B, H, W, Hp, Wp, win[0],
                                    win[1], kwin[0], kwin[1], shift[0], shift[1], int(use_mask), heads, d, float(scale),
                                    _stream()))
+    nwin = B * (Hp // win[0]) * (Wp // win[1])
+    _note(4.0 * nwin * heads * 256 * nk * d, 4.0 * (4.0 * B * H * W * heads * d + heads * nk * 256))
     return out
 
 
@@ -142,6 +194,7 @@ def layernorm(x: T, gamma: T, beta: T, eps: float = 1e-5, out: Optional[T] = Non
     if orows != rows or oc != C or gamma.numel() != C or beta.numel() != C:
         raise _lib.FFError("layernorm: shape mismatch")
     _lib.check(_L().ff_layernorm(xp, ldi, op, ldo, rows, C, gamma.data_ptr(), beta.data_ptr(), float(eps), _stream()))
+    _note(0.0, 8.0 * rows * C)
     return out
 
 
@@ -153,6 +206,7 @@ def pool_mean(x: T) -> T:
     work = torch.empty(nwork, device=x.device, dtype=torch.float32)
     out = torch.empty((B, C), device=x.device, dtype=torch.float32)
     _lib.check(_L().ff_pool_mean(xp, ld, B, P, C, out.data_ptr(), work.data_ptr(), nwork, _stream()))
+    _note(0.0, 4.0 * B * P * C)
     return out
 
 
@@ -182,6 +236,7 @@ def dwconv2d(x: T, w_tap: T, bias: Optional[T] = None, *, ksize=(3, 3), stride=(
     op, ldo, *_ = _nhwc(out, "dwconv2d.out")
     _lib.check(_L().ff_dwconv2d(xp, ldi, op, ldo, B, H, W, C, Ho, Wo, w_tap.data_ptr(), _ptr(bias), KH, KW, stride[0],
                                 stride[1], pad[0], pad[1], _ptr(post_scale), _ptr(post_shift), ACT[act], _stream()))
+    _note(2.0 * B * Ho * Wo * C * KH * KW, 4.0 * (B * H * W * C + B * Ho * Wo * C))
     return out
 
 
@@ -215,6 +270,7 @@ def mix2(a: T, b: Optional[T] = None, *, ka: float = 1.0, kb: float = 1.0, ca: O
             raise _lib.FFError(f"mix2: {nm} must have {C} elements")
     _lib.check(_L().ff_mix2(op, ldo, ap, lda, bp, ldb, rows, C, float(ka), float(kb), _ptr(ca), _ptr(cb), pap, ldpa, pbp,
                             ldpb, int(clamp01), _stream()))
+    _note(0.0, 4.0 * rows * C * (3 if b is not None else 2))
     return out
 
 
@@ -234,6 +290,7 @@ def fma3(a: Optional[T], b: T, c: T, alpha: float = 1.0, out: Optional[T] = None
     if orows != rows or oc != C:
         raise _lib.FFError("fma3: out shape mismatch")
     _lib.check(_L().ff_fma3(op, ldo, ap, lda, bp, ldb, cp, ldc, rows, C, float(alpha), _stream()))
+    _note(0.0, 4.0 * rows * C * (4 if a is not None else 3))
     return out
 
 
@@ -245,6 +302,7 @@ def affine(x: T, scale: T, shift: T, act=None, out: Optional[T] = None) -> T:
     if orows != rows or oc != C or scale.numel() != C or shift.numel() != C:
         raise _lib.FFError("affine: shape mismatch")
     _lib.check(_L().ff_affine(op, ldo, xp, ldi, rows, C, scale.data_ptr(), shift.data_ptr(), ACT[act], _stream()))
+    _note(0.0, 8.0 * rows * C)
     return out
 
 
@@ -300,6 +358,7 @@ def resize(x: T, size: Tuple[int, int], *, mode: str = "bilinear", scale_factor:
     sw = _aten_scale(Wi, Wo, scale_factor)
     _lib.check(_L().ff_resize(xp, isb, isc, isy, isx, Hi, Wi, op, oh * ow * ldo, 1, ow * ldo, ldo, Ho, Wo, B, C, sh, sw,
                               0 if mode == "bilinear" else 1, float(mul), _stream()))
+    _note(0.0, 4.0 * B * C * (Hi * Wi + Ho * Wo))
     return out
 
 
@@ -404,3 +463,9 @@ def tile_accum(tile: T, wy: T, wx: T, acc: T, wsum: T, sy: int, sx: int):
 def tile_normalize(acc: T, wsum: T):
     _, C, H, W = acc.shape
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
+
+
+for _n in ("conv2d", "linear", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
+           "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights",
+           "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
+    globals()[_n] = _instrument(globals()[_n])
