@@ -63,30 +63,42 @@ __global__ __launch_bounds__(384) void chan_gram_kernel(const float* __restrict_
   }
 }
 
-// one workgroup: sum partials, normalise, softmax rows, emit block-diagonal weight Wbd[co][ci]
-__global__ __launch_bounds__(256) void chan_attn_weights_kernel(const float* __restrict__ part, int nblk,
+// stage 2: many workgroups sum the per-block partials (coalesced over the 5760 statistics)
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ part, int nblk, float* __restrict__ G) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 5760) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblk; b += 4) {
+    s0 += part[(long long)b * 5760 + e];
+    s1 += part[(long long)(b + 1) * 5760 + e];
+    s2 += part[(long long)(b + 2) * 5760 + e];
+    s3 += part[(long long)(b + 3) * 5760 + e];
+  }
+  for (; b < nblk; ++b) s0 += part[(long long)b * 5760 + e];
+  G[e] = (s0 + s1) + (s2 + s3);
+}
+
+// stage 3: normalise, softmax rows, emit block-diagonal weight Wbd[co][ci] (one thread per (row, column))
+__global__ __launch_bounds__(256) void chan_attn_weights_kernel(const float* __restrict__ G,
                                                                 const float* __restrict__ temperature,
                                                                 float* __restrict__ wbd) {
-  __shared__ float G[5760];
-  for (int e = threadIdx.x; e < 5760; e += 256) {
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long long)b * 5760 + e];
-    G[e] = s;
+  const int row = blockIdx.x;                                // head*30 + i
+  const int head = row / 30, i = row % 30;
+  __shared__ float v[30];
+  const float nq = fmaxf(sqrtf(G[5400 + row]), 1e-12f);
+  if (threadIdx.x < 30) {
+    const int j = threadIdx.x;
+    const float nk = fmaxf(sqrtf(G[5400 + 180 + head * 30 + j]), 1e-12f);
+    v[j] = G[head * 900 + i * 30 + j] / (nq * nk) * temperature[head];
   }
-  for (int e = threadIdx.x; e < 180 * 180; e += 256) wbd[e] = 0.f;
   __syncthreads();
-  for (int row = threadIdx.x; row < 180; row += 256) {     // row = head*30 + i
-    const int head = row / 30;
-    const float nq = fmaxf(sqrtf(G[5400 + row]), 1e-12f);
-    float v[30], mx = -INFINITY;
-    for (int j = 0; j < 30; ++j) {
-      const float nk = fmaxf(sqrtf(G[5400 + 180 + head * 30 + j]), 1e-12f);
-      v[j] = G[head * 900 + (row % 30) * 30 + j] / (nq * nk) * temperature[head];
-      mx = fmaxf(mx, v[j]);
-    }
-    float s = 0.f;
-    for (int j = 0; j < 30; ++j) { v[j] = expf(v[j] - mx); s += v[j]; }
-    for (int j = 0; j < 30; ++j) wbd[row * 180 + head * 30 + j] = v[j] / s;
+  float mx = -INFINITY, s = 0.f;
+  for (int j = 0; j < 30; ++j) mx = fmaxf(mx, v[j]);
+  for (int j = 0; j < 30; ++j) s += expf(v[j] - mx);
+  for (int c = threadIdx.x; c < 180; c += blockDim.x) {
+    const int j = c - head * 30;
+    wbd[row * 180 + c] = (j >= 0 && j < 30) ? expf(v[j] - mx) / s : 0.f;
   }
 }
 
@@ -97,10 +109,12 @@ extern "C" int ff_chan_attn_weights(const float* qkv, int ld, int q_off, int k_o
   if (nblk > 1024) nblk = 1024;
   const int tpb = (int)((N + nblk - 1) / nblk);
   nblk = (int)((N + tpb - 1) / tpb);
-  FF_CHECK_ARG(work_floats >= (long long)nblk * 5760, "ff_chan_attn_weights: workspace too small (need %lld floats)", (long long)nblk * 5760);
+  FF_CHECK_ARG(work_floats >= (long long)(nblk + 1) * 5760, "ff_chan_attn_weights: workspace too small (need %lld floats)", (long long)(nblk + 1) * 5760);
   hipStream_t st = (hipStream_t)stream;
+  float* G = work + (long long)nblk * 5760;
   hipLaunchKernelGGL(chan_gram_kernel, dim3(nblk), dim3(384), 0, st, qkv, ld, q_off, k_off, N, tpb, work);
-  hipLaunchKernelGGL(chan_attn_weights_kernel, dim3(1), dim3(256), 0, st, work, nblk, temperature, wbd);
+  hipLaunchKernelGGL(chan_reduce_kernel, dim3((5760 + 255) / 256), dim3(256), 0, st, work, nblk, G);
+  hipLaunchKernelGGL(chan_attn_weights_kernel, dim3(180), dim3(64), 0, st, G, temperature, wbd);
   FF_LAUNCH_CHECK("ff_chan_attn_weights");
   return FF_OK;
 }
@@ -108,7 +122,7 @@ extern "C" int ff_chan_attn_weights(const float* qkv, int ld, int q_off, int k_o
 extern "C" long long ff_chan_attn_workspace(long long N) {
   long long nblk = (N + 255) / 256;
   if (nblk > 1024) nblk = 1024;
-  return (nblk + 1) * 5760;
+  return (nblk + 2) * 5760;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -69,6 +69,45 @@ extern "C" int ff_layernorm(const float* in, int ldi, float* out, int ldo, long 
 
 // ---------------------------------------------------------------------------------------------
 // pool: stage 1 = per-chunk column sums, stage 2 = sum of chunks / P.  Deterministic (no atomics).
+// Stage 1 (C % 4 == 0): a thread owns one float4 column and walks pixels with 4 independent loads in flight.
+__global__ __launch_bounds__(256) void pool_partial_v4_kernel(const float* __restrict__ in, int ld, long long P, int C,
+                                                              int pix_per_chunk, float* __restrict__ part) {
+  extern __shared__ float4 red4[];                           // [rpi][cv]
+  const int cv = C >> 2, rpi = 256 / cv;                     // float4 columns, pixel rows per iteration
+  const int col = threadIdx.x % cv, row = threadIdx.x / cv;
+  const int chunk = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
+  const long long p0 = (long long)chunk * pix_per_chunk;
+  long long p1 = p0 + pix_per_chunk;
+  if (p1 > P) p1 = P;
+  const float* base = in + (long long)b * P * ld + 4 * col;
+  float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  if (row < rpi) {
+    long long pp = p0 + row;
+    for (; pp + 3LL * rpi < p1; pp += 4LL * rpi) {
+      const float4 v0 = *reinterpret_cast<const float4*>(base + pp * ld);
+      const float4 v1 = *reinterpret_cast<const float4*>(base + (pp + rpi) * ld);
+      const float4 v2 = *reinterpret_cast<const float4*>(base + (pp + 2LL * rpi) * ld);
+      const float4 v3 = *reinterpret_cast<const float4*>(base + (pp + 3LL * rpi) * ld);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; pp < p1; pp += rpi) {
+      const float4 v0 = *reinterpret_cast<const float4*>(base + pp * ld);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    a0.x += a1.x + a2.x + a3.x; a0.y += a1.y + a2.y + a3.y; a0.z += a1.z + a2.z + a3.z; a0.w += a1.w + a2.w + a3.w;
+    red4[row * cv + col] = a0;
+  }
+  __syncthreads();
+  if (row == 0) {
+    float4 s = red4[col];
+    for (int r = 1; r < rpi; ++r) { const float4 t = red4[r * cv + col]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    *reinterpret_cast<float4*>(part + ((long long)b * nch + chunk) * C + 4 * col) = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ in, int ld, long long P, int C,
                                                            int pix_per_chunk, float* __restrict__ part) {
   __shared__ float red[4][64];
@@ -90,12 +129,27 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
   }
 }
 
-__global__ void pool_final_kernel(const float* __restrict__ part, int nch, int C, float invP, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int i = 0; i < nch; ++i) s += part[((long long)b * nch + i) * C + c];
-  out[(long long)b * C + c] = s * invP;
+// stage 2: 64 channels x 4 partial-lanes per workgroup, 4 independent accumulators per thread
+__global__ __launch_bounds__(256) void pool_final_kernel(const float* __restrict__ part, int nch, int C, float invP,
+                                                         float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    const float* pp = part + (long long)b * nch * C + c;
+    int i = r;
+    for (; i + 12 < nch; i += 16) {
+      s0 += pp[(long long)i * C];
+      s1 += pp[(long long)(i + 4) * C];
+      s2 += pp[(long long)(i + 8) * C];
+      s3 += pp[(long long)(i + 12) * C];
+    }
+    for (; i < nch; i += 4) s0 += pp[(long long)i * C];
+  }
+  red[r][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (r == 0 && c < C) out[(long long)b * C + c] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * invP;
 }
 
 extern "C" int ff_pool_mean(const float* in, int ld, int B, long long P, int C, float* out, float* work,
@@ -103,13 +157,19 @@ extern "C" int ff_pool_mean(const float* in, int ld, int B, long long P, int C, 
   FF_CHECK_ARG(in && out && work, "ff_pool_mean: null pointer");
   FF_CHECK_ARG(B > 0 && P > 0 && C > 0 && ld >= C, "ff_pool_mean: bad dims");
   int nch = (int)((P + 255) / 256);
-  if (nch > 512) nch = 512;
+  if (nch > 1024) nch = 1024;
   const int ppc = (int)((P + nch - 1) / nch);
   nch = (int)((P + ppc - 1) / ppc);
   FF_CHECK_ARG(work_floats >= (long long)B * nch * C, "ff_pool_mean: workspace too small (need %lld floats)", (long long)B * nch * C);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pool_partial_kernel, dim3(nch, B), dim3(256), 0, st, in, ld, P, C, ppc, work);
-  hipLaunchKernelGGL(pool_final_kernel, dim3((C + 255) / 256, B), dim3(256), 0, st, work, nch, C, 1.0f / (float)P, out);
+  const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && (C / 4 <= 256) && (((uintptr_t)in & 15) == 0) && (((uintptr_t)work & 15) == 0);
+  if (v4) {
+    const int cv = C / 4, rpi = 256 / cv;
+    hipLaunchKernelGGL(pool_partial_v4_kernel, dim3(nch, B), dim3(256), (size_t)rpi * cv * 16, st, in, ld, P, C, ppc, work);
+  } else {
+    hipLaunchKernelGGL(pool_partial_kernel, dim3(nch, B), dim3(256), 0, st, in, ld, P, C, ppc, work);
+  }
+  hipLaunchKernelGGL(pool_final_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, work, nch, C, 1.0f / (float)P, out);
   FF_LAUNCH_CHECK("ff_pool_mean");
   return FF_OK;
 }
@@ -117,7 +177,7 @@ extern "C" int ff_pool_mean(const float* in, int ld, int B, long long P, int C, 
 // workspace floats ff_pool_mean needs for (B, P, C)
 extern "C" long long ff_pool_mean_workspace(int B, long long P, int C) {
   long long nch = (P + 255) / 256;
-  if (nch > 512) nch = 512;
+  if (nch > 1024) nch = 1024;
   return (long long)B * (nch + 1) * C;
 }
 
