@@ -1,0 +1,318 @@
+// Implicit-GEMM convolution / GEMM on the bf16 matrix cores with fp32-grade accuracy by operand
+// splitting ("bf16x3"):  a = a_hi + a_lo (+ O(2^-16 |a|)),  both halves bf16, so
+//     a*w  ~=  a_hi*w_hi + a_lo*w_hi + a_hi*w_lo          (the dropped a_lo*w_lo term is O(2^-16))
+// Each term is one v_mfma_f32_32x32x16_bf16 into the SAME fp32 accumulator: 3 MFMAs at 16x the fp32
+// MFMA rate = 5.3x the fp32-MFMA ceiling of conv_gemm.hip at the same results to ~1e-5 relative.
+// NTERMS = 1 (plain bf16) and 2 (fp32-accurate activations x bf16 weights) are the cheaper modes.
+//
+// Same contract / epilogue as conv_gemm.hip.  Differences:
+//   - weights arrive pre-split by ff_split_bf16 as two bf16 planes w_hi/w_lo [Cout][Kp], Kp = K rounded up
+//     to 32 (zero filled), so the B tile is a straight 16-byte copy with no K tail;
+//   - activations are split on the fly in the staging path (v_cvt_pk_bf16_f32), once per element per
+//     workgroup, and stored to LDS as [row][hi k0..31 | lo k0..31] (128 B + 16 B pad = 36 dwords:
+//     36 = 4*9 puts the 16 rows of a ds_read_b128 lane group on 16 distinct 4-bank slots);
+//   - BK = 32: two k-steps of the 32x32x16 MFMA per chunk; a lane's operand is one ds_read_b128
+//     (8 consecutive k of its row) per plane and k-step.
+#include "ff_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct ConvBfParams {
+  const float* in;
+  const __bf16* w_hi;
+  const __bf16* w_lo;
+  const float* bias;
+  const float* mul;
+  const float* res;
+  float* out;
+  int B, H, W, Cin, ldi;
+  int Ho, Wo, Cout, ldo, ldr;
+  int KH, KW, sy, sx, py, px;
+  int K, Kp, M;
+  int act;
+  float alpha;
+  int shuffle;
+};
+
+#define ROWB 144   // bytes per LDS row: 64 hi + 64 lo + 16 pad
+#define BKB 32
+
+template <int BM, int BN, int WM, int WN, bool VEC4, int NTERMS>
+__global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvBfParams p) {
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int AQ = BM / 32;                     // A quads (4 k-values) staged per thread: BM*8/256
+  constexpr int BI = (BN * 8 + 255) / 256;        // B 16-byte items staged per thread (hi+lo planes)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;                       // [2][BM][ROWB]
+  unsigned char* Bs = smem + 2 * BM * ROWB;       // [2][BN][ROWB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wr = wid / WN, wc = wid % WN;
+
+  const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
+  const int L = ff_xcd_remap(blockIdx.x, mtiles * ntiles);
+  const int m0 = (L / ntiles) * BM, n0 = (L % ntiles) * BN;
+
+  const int srow = tid >> 3, kq = tid & 7;        // A staging: row srow + 32*i, k-quad kq
+  int a_b[AQ], a_iy[AQ], a_ix[AQ];
+  bool a_ok[AQ];
+#pragma unroll
+  for (int i = 0; i < AQ; ++i) {
+    const int m = m0 + srow + 32 * i;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int ox = mm % p.Wo, t2 = mm / p.Wo;
+    const int oy = t2 % p.Ho;
+    a_b[i] = t2 / p.Ho;
+    a_iy[i] = oy * p.sy - p.py;
+    a_ix[i] = ox * p.sx - p.px;
+  }
+  const bool is1x1 = (p.KH == 1 && p.KW == 1);
+
+  f32x4 ra[AQ];
+  uint4 rb[BI];
+
+  auto load_chunk = [&](int k0) {
+    if (VEC4) {
+      const int k = k0 + 4 * kq;
+      const bool kok = k < p.K;
+      int ky = 0, kx = 0, ci = k;
+      if (!is1x1 && kok) {
+        const int tap = k / p.Cin;
+        ci = k - tap * p.Cin;
+        ky = tap / p.KW;
+        kx = tap - ky * p.KW;
+      }
+#pragma unroll
+      for (int i = 0; i < AQ; ++i) {
+        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kok && a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          v = *reinterpret_cast<const f32x4*>(p.in + ((long long)(a_b[i] * p.H + iy) * p.W + ix) * p.ldi + ci);
+        ra[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = k0 + 4 * kq + e;
+        const bool kok = k < p.K;
+        int ky = 0, kx = 0, ci = k;
+        if (!is1x1 && kok) {
+          const int tap = k / p.Cin;
+          ci = k - tap * p.Cin;
+          ky = tap / p.KW;
+          kx = tap - ky * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < AQ; ++i) {
+          const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+          float v = 0.f;
+          if (kok && a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            v = p.in[((long long)(a_b[i] * p.H + iy) * p.W + ix) * p.ldi + ci];
+          ra[i][e] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+      const int id = tid + 256 * j;                // [plane][row][q]
+      const int plane = id / (BN * 4), rem = id % (BN * 4);
+      const int r = rem >> 2, q = rem & 3;
+      uint4 v = {0u, 0u, 0u, 0u};
+      if (id < BN * 8 && (NTERMS == 3 || plane == 0) && n0 + r < p.Cout) {
+        const __bf16* src = (plane ? p.w_lo : p.w_hi) + (long long)(n0 + r) * p.Kp + k0 + 8 * q;
+        v = *reinterpret_cast<const uint4*>(src);
+      }
+      rb[j] = v;
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AQ; ++i) {
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float f = ra[i][e];
+        const __bf16 h = (__bf16)f;
+        hi[e] = h;
+        lo[e] = (__bf16)(f - (float)h);
+      }
+      unsigned char* dst = As + (size_t)(buf * BM + srow + 32 * i) * ROWB + kq * 8;
+      *reinterpret_cast<bf16x4*>(dst) = hi;
+      if (NTERMS >= 2) *reinterpret_cast<bf16x4*>(dst + 64) = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+      const int id = tid + 256 * j;
+      const int plane = id / (BN * 4), rem = id % (BN * 4);
+      const int r = rem >> 2, q = rem & 3;
+      if (id < BN * 8 && (NTERMS == 3 || plane == 0))
+        *reinterpret_cast<uint4*>(Bs + (size_t)(buf * BN + r) * ROWB + plane * 64 + q * 16) = rb[j];
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = p.Kp / BKB;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) load_chunk((c + 1) * BKB);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const unsigned char* ap = As + (size_t)(buf * BM + wr * TM + i * 32 + l31) * ROWB + 32 * s + 16 * hh;
+        ah[i] = *reinterpret_cast<const bf16x8*>(ap);
+        if (NTERMS >= 2) al[i] = *reinterpret_cast<const bf16x8*>(ap + 64);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const unsigned char* bp = Bs + (size_t)(buf * BN + wc * TN + j * 32 + l31) * ROWB + 32 * s + 16 * hh;
+        bh[j] = *reinterpret_cast<const bf16x8*>(bp);
+        if (NTERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(bp + 64);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          if (NTERMS == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if (NTERMS >= 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wc * TN + j * 32 + l31;
+    if (n >= p.Cout) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+    const float mv = (p.mul ? p.mul[n] : 1.f) * p.alpha;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m >= p.M) continue;
+        float v = ff_act(acc[i][j][r] + bv, p.act) * mv;
+        long long oidx, ridx;
+        if (p.shuffle == 2) {
+          const int ox = m % p.Wo, t2 = m / p.Wo;
+          const int oy = t2 % p.Ho, b = t2 / p.Ho;
+          const int co = n >> 2, dy = (n >> 1) & 1, dx = n & 1;
+          const long long pix = ((long long)(b * 2 * p.Ho + 2 * oy + dy) * (2 * p.Wo) + 2 * ox + dx);
+          oidx = pix * p.ldo + co;
+          ridx = pix * p.ldr + co;
+        } else {
+          oidx = (long long)m * p.ldo + n;
+          ridx = (long long)m * p.ldr + n;
+        }
+        if (p.res) v += p.res[ridx];
+        p.out[oidx] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NT>
+static int launch_bf(const ConvBfParams& p, bool vec4, hipStream_t st) {
+  const int mt = ff_cdiv(p.M, BM), nt = ff_cdiv(p.Cout, BN);
+  const size_t lds = (size_t)2 * (BM + BN) * ROWB;
+  dim3 grid((unsigned)(mt * nt)), block(256);
+  if (vec4)
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, true, NT>), grid, block, lds, st, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, false, NT>), grid, block, lds, st, p);
+  FF_LAUNCH_CHECK("ff_conv2d_bf16s");
+  return FF_OK;
+}
+
+template <int NT>
+static int dispatch_bf(const ConvBfParams& p, bool vec4, int cfg, hipStream_t st) {
+  switch (cfg) {
+    case 1: return launch_bf<128, 128, 2, 2, NT>(p, vec4, st);
+    case 2: return launch_bf<128, 64, 2, 2, NT>(p, vec4, st);
+    case 3: return launch_bf<256, 32, 4, 1, NT>(p, vec4, st);
+    default: ff_set_error("ff_conv2d_bf16s: bad tile_hint %d", cfg); return FF_ERR_ARG;
+  }
+}
+
+extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_lo, int Kp, const float* bias,
+                               const float* mul, const float* res, float* out, int B, int H, int W, int Cin, int ldi,
+                               int Ho, int Wo, int Cout, int ldo, int ldr, int KH, int KW, int sy, int sx, int py, int px,
+                               int act, float alpha, int shuffle, int nterms, int tile_hint, void* stream) {
+  FF_CHECK_ARG(in && w_hi && out, "ff_conv2d_bf16s: null pointer");
+  FF_CHECK_ARG(nterms >= 1 && nterms <= 3 && (nterms < 3 || w_lo), "ff_conv2d_bf16s: nterms must be 1..3 (3 needs w_lo)");
+  FF_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "ff_conv2d_bf16s: bad dims");
+  FF_CHECK_ARG(ldi >= Cin, "ff_conv2d_bf16s: ldi %d < Cin %d", ldi, Cin);
+  FF_CHECK_ARG(KH > 0 && KW > 0 && sy > 0 && sx > 0 && py >= 0 && px >= 0, "ff_conv2d_bf16s: bad kernel geometry");
+  FF_CHECK_ARG(Kp % 32 == 0 && Kp >= KH * KW * Cin, "ff_conv2d_bf16s: Kp must be K rounded up to 32");
+  FF_CHECK_ARG((((uintptr_t)w_hi) & 15) == 0 && (!w_lo || (((uintptr_t)w_lo) & 15) == 0), "ff_conv2d_bf16s: weight planes must be 16-byte aligned");
+  FF_CHECK_ARG(shuffle == 0 || shuffle == 2, "ff_conv2d_bf16s: shuffle must be 0 or 2");
+  FF_CHECK_ARG(shuffle == 0 || Cout % 4 == 0, "ff_conv2d_bf16s: shuffle needs Cout %% 4 == 0");
+  FF_CHECK_ARG(ldo >= (shuffle ? Cout / 4 : Cout), "ff_conv2d_bf16s: ldo too small");
+  FF_CHECK_ARG(!res || ldr >= (shuffle ? Cout / 4 : Cout), "ff_conv2d_bf16s: ldr too small");
+  FF_CHECK_ARG((long long)B * Ho * Wo < (1LL << 31), "ff_conv2d_bf16s: M overflows int");
+  ConvBfParams p;
+  p.in = in; p.w_hi = (const __bf16*)w_hi; p.w_lo = (const __bf16*)w_lo; p.bias = bias; p.mul = mul; p.res = res; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.ldi = ldi;
+  p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.ldo = ldo; p.ldr = ldr;
+  p.KH = KH; p.KW = KW; p.sy = sy; p.sx = sx; p.py = py; p.px = px;
+  p.K = KH * KW * Cin; p.Kp = Kp; p.M = B * Ho * Wo;
+  p.act = act; p.alpha = alpha; p.shuffle = shuffle;
+  const bool vec4 = (Cin % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)in & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  int cfg = tile_hint;
+  if (cfg <= 0) {
+    // measured on MI355X (profiles/r01_gemm_shapes_bf16x3_v2.txt): 128x128 tiles win whenever N pads well or K is long
+    if (Cout <= 32) cfg = 3;
+    else if (Cout % 128 == 0 || Cout > 256 || (Cout > 128 && p.K >= 512)) cfg = 1;
+    else cfg = 2;
+  }
+  switch (nterms) {
+    case 1: return dispatch_bf<1>(p, vec4, cfg, st);
+    case 2: return dispatch_bf<2>(p, vec4, cfg, st);
+    default: return dispatch_bf<3>(p, vec4, cfg, st);
+  }
+}
+
+// fp32 [N][K] -> bf16 planes hi/lo [N][Kp] (Kp = K rounded up to 32, zero filled); lo may be NULL
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ w, int N, int K, int Kp, __bf16* __restrict__ hi,
+                                                         __bf16* __restrict__ lo) {
+  const long long total = (long long)N * Kp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % Kp);
+    const long long n = i / Kp;
+    const float f = k < K ? w[n * K + k] : 0.f;
+    const __bf16 h = (__bf16)f;
+    hi[i] = h;
+    if (lo) lo[i] = (__bf16)(f - (float)h);
+  }
+}
+
+extern "C" int ff_split_bf16(const float* w, int N, int K, int Kp, void* hi, void* lo, void* stream) {
+  FF_CHECK_ARG(w && hi && N > 0 && K > 0 && Kp % 32 == 0 && Kp >= K, "ff_split_bf16: bad args");
+  long long nb = ((long long)N * Kp + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, N, K, Kp, (__bf16*)hi, (__bf16*)lo);
+  FF_LAUNCH_CHECK("ff_split_bf16");
+  return FF_OK;
+}

@@ -273,7 +273,7 @@ class DatHIP:
             ch_in, sp_in = conv_x, att
         else:
             wbd = ops.chan_attn_weights(qkv, 0, C, blk["temp"])
-            att = ops.linear(v, wbd)
+            att = ops.linear(v, wbd, dynamic_w=True)
             ch_in, sp_in = att, conv_x
         cm = ops.vec_mlp(ops.pool_mean(ch_in), *blk["ci1"], "gelu", *blk["ci4"], "sigmoid")              # [1,C]
         sm = ops.linear(ops.linear(sp_in, *blk["si0"], act="gelu"), *blk["si3"], act="sigmoid")          # [1,H,W,1]
@@ -348,7 +348,7 @@ class NafnetHIP:
         g = ops.fma3(None, t[..., :c], t[..., c:])                          # SimpleGate
         sca = ops.vec_mlp(ops.pool_mean(g), *k["sca"], None)                # [1,c]
         w3 = ops.mix2(k["c3"][0], ca=sca.reshape(-1))                       # conv3(g * sca) == (W3 . diag(sca)) g
-        y = ops.linear(g, w3, k["c3"][1], res=x, mul=k["beta"])
+        y = ops.linear(g, w3, k["c3"][1], res=x, mul=k["beta"], dynamic_w=True)
         t = ops.linear(ops.layernorm(y, *k["n2"], eps=1e-6), *k["c4"])
         g = ops.fma3(None, t[..., :c], t[..., c:])
         return ops.linear(g, *k["c5"], res=y, mul=k["gamma"])

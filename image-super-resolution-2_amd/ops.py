@@ -70,6 +70,44 @@ def _L():
     return _lib.load()
 
 
+# ---- contraction precision ---------------------------------------------------------------------------
+# "f32"    : v_mfma_f32_32x32x2_f32, exact fp32 fma chain (parity mode, 157 TFLOP/s ceiling)
+# "bf16x3" : split-operand bf16 MFMA, 3 terms, fp32-grade results (default; 833 TFLOP/s algorithmic ceiling)
+# "bf16x2" : exact activations x bf16 weights;  "bf16": plain bf16 operands, fp32 accumulate
+import os as _os
+
+GEMM_MODES = {"f32": 0, "bf16": 1, "bf16x2": 2, "bf16x3": 3}
+_GEMM_MODE = _os.environ.get("FF_GEMM", "bf16x3")
+
+
+def set_gemm_mode(mode: str):
+    global _GEMM_MODE
+    if mode not in GEMM_MODES:
+        raise _lib.FFError(f"unknown GEMM mode {mode!r}; expected one of {sorted(GEMM_MODES)}")
+    _GEMM_MODE = mode
+
+
+def gemm_mode() -> str:
+    return _GEMM_MODE
+
+
+def _split_weight(w: T, dynamic: bool):
+    """bf16 hi/lo planes [N][Kp] of a packed fp32 weight; cached on the tensor object unless `dynamic`."""
+    nterms = GEMM_MODES[_GEMM_MODE]
+    cached = None if dynamic else getattr(w, "_ff_split", None)
+    if cached is not None and cached[3] >= nterms:
+        return cached
+    N, K = w.shape
+    Kp = (K + 31) // 32 * 32
+    hi = torch.empty((N, Kp), device=w.device, dtype=torch.bfloat16)
+    lo = torch.empty((N, Kp), device=w.device, dtype=torch.bfloat16) if nterms == 3 else None
+    _lib.check(_L().ff_split_bf16(w.data_ptr(), N, K, Kp, hi.data_ptr(), lo.data_ptr() if lo is not None else None, _stream()))
+    ent = (hi, lo, Kp, nterms)
+    if not dynamic:
+        w._ff_split = ent
+    return ent
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -114,7 +152,7 @@ def _nhwc(t: T, name: str):
 
 def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1), pad=(0, 0), act=None,
            res: Optional[T] = None, mul: Optional[T] = None, alpha: float = 1.0, shuffle: int = 0,
-           out: Optional[T] = None, tile_hint: int = 0) -> T:
+           out: Optional[T] = None, tile_hint: int = 0, dynamic_w: bool = False) -> T:
     """x [B,H,W,Cin] (rows view), w packed [Cout, KH*KW*Cin] -> [B,Ho,Wo,Cout] (or pixel-shuffled)."""
     xp, ldi, B, H, W, Cin = _nhwc(x, "conv2d.x")
     KH, KW = ksize
@@ -134,15 +172,22 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
         if tuple(res.shape) != oshape:
             raise _lib.FFError(f"conv2d: res shape {tuple(res.shape)} != {oshape}")
         rp, ldr, *_ = _nhwc(res, "conv2d.res")
-    _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, B, H, W, Cin, ldi, Ho, Wo, Cout, ldo, ldr,
-                              KH, KW, stride[0], stride[1], pad[0], pad[1], ACT[act], float(alpha), shuffle, tile_hint,
-                              _stream()))
+    if _GEMM_MODE == "f32":
+        _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, B, H, W, Cin, ldi, Ho, Wo, Cout, ldo, ldr,
+                                  KH, KW, stride[0], stride[1], pad[0], pad[1], ACT[act], float(alpha), shuffle, tile_hint,
+                                  _stream()))
+    else:
+        hi, lo, Kp, _ = _split_weight(w, dynamic_w)
+        _lib.check(_L().ff_conv2d_bf16s(xp, hi.data_ptr(), lo.data_ptr() if lo is not None else None, Kp, _ptr(bias), _ptr(mul),
+                                        rp, op, B, H, W, Cin, ldi, Ho, Wo, Cout, ldo, ldr, KH, KW, stride[0], stride[1],
+                                        pad[0], pad[1], ACT[act], float(alpha), shuffle, GEMM_MODES[_GEMM_MODE], tile_hint,
+                                        _stream()))
     _note(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, 4.0 * (_numel(x, w, out, res)))
     return out
 
 
 def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] = None, mul: Optional[T] = None,
-           alpha: float = 1.0, out: Optional[T] = None) -> T:
+           alpha: float = 1.0, out: Optional[T] = None, dynamic_w: bool = False) -> T:
     """x [..., K] rows view, w [N, K] -> [..., N]."""
     xp, ldi, rows, K = rows_view(x, "linear.x")
     N = w.shape[0]
@@ -159,8 +204,14 @@ def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] =
         rp, ldr, rrows, rc = rows_view(res, "linear.res")
         if rrows != rows or rc != N:
             raise _lib.FFError("linear: res shape mismatch")
-    _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, 1, 1, rows, K, ldi, 1, rows, N, ldo, ldr,
-                              1, 1, 1, 1, 0, 0, ACT[act], float(alpha), 0, 0, _stream()))
+    if _GEMM_MODE == "f32":
+        _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, 1, 1, rows, K, ldi, 1, rows, N, ldo, ldr,
+                                  1, 1, 1, 1, 0, 0, ACT[act], float(alpha), 0, 0, _stream()))
+    else:
+        hi, lo, Kp, _ = _split_weight(w, dynamic_w)
+        _lib.check(_L().ff_conv2d_bf16s(xp, hi.data_ptr(), lo.data_ptr() if lo is not None else None, Kp, _ptr(bias), _ptr(mul),
+                                        rp, op, 1, 1, rows, K, ldi, 1, rows, N, ldo, ldr, 1, 1, 1, 1, 0, 0, ACT[act],
+                                        float(alpha), 0, GEMM_MODES[_GEMM_MODE], 0, _stream()))
     _note(2.0 * rows * N * K, 4.0 * (rows * K + N * K + rows * N * (2 if res is not None else 1)))
     return out
 

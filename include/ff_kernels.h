@@ -45,6 +45,17 @@ int ff_conv2d(const float* in, const float* w, const float* bias, const float* m
               int B, int H, int W, int Cin, int ldi, int Ho, int Wo, int Cout, int ldo, int ldr, int KH, int KW,
               int sy, int sx, int py, int px, int act, float alpha, int shuffle, int tile_hint, void* stream);
 
+/* Same contraction on the bf16 matrix cores with split operands ("bf16x3", csrc/conv_gemm_bf16.hip):
+ * a*w ~= a_hi*w_hi + a_lo*w_hi + a_hi*w_lo, every term one v_mfma_f32_32x32x16_bf16 into the same fp32
+ * accumulator.  nterms 3 = fp32-grade (~1e-5 rel), 2 = exact activations x bf16 weights, 1 = plain bf16.
+ * w_hi / w_lo are bf16 planes [Cout][Kp] (Kp = KH*KW*Cin rounded up to 32, zero filled) made by ff_split_bf16
+ * (lo may be NULL for nterms < 3).  Everything else as ff_conv2d. */
+int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_lo, int Kp, const float* bias, const float* mul,
+                    const float* res, float* out, int B, int H, int W, int Cin, int ldi, int Ho, int Wo, int Cout,
+                    int ldo, int ldr, int KH, int KW, int sy, int sx, int py, int px, int act, float alpha, int shuffle,
+                    int nterms, int tile_hint, void* stream);
+int ff_split_bf16(const float* w, int N, int K, int Kp, void* hi, void* lo, void* stream);
+
 /* Fused window attention softmax((q*scale) k^T + bias (+mask)) v on fp32 MFMA; one workgroup per
  * (window, head).  qkv is the token tensor [B][H][W][ldq]; q/k/v of head h live at *_off + h*d.
  * Queries: wh x ww windows (wh*ww == 256) on the (Hp, Wp) zero-padded grid, cyclically shifted by

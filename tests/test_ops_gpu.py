@@ -22,6 +22,19 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def gemm_mode(request, dev):
+    """Contraction precision of ff_conv2d: exact fp32 MFMA, or the split-operand bf16 MFMA (default)."""
+    from isr2_amd import ops
+    old = ops.gemm_mode()
+    ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode(old)
+
+
+GEMM_TOL = {"f32": 2e-5, "bf16x3": 6e-5}   # relative to max|ref|; bf16x3 drops the O(2^-16) lo*lo term
+
+
 def rnd(*shape, dev, seed=0, scale=1.0):
     g = torch.Generator(device="cpu").manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).to(dev)
@@ -44,7 +57,7 @@ def close(a, b, tol, name=""):
     (1, 8, 8, 1024, 2048, 1, 1, 0, None),      # 128x128 tile config
     (1, 24, 24, 32, 1, 3, 1, 1, "sigmoid"),
 ])
-def test_conv2d_matches_torch(dev, B, H, W, Cin, Cout, k, s, p, act):
+def test_conv2d_matches_torch(dev, gemm_mode, B, H, W, Cin, Cout, k, s, p, act):
     from isr2_amd import ops
     from isr2_amd.prep import pack_conv
     x = rnd(B, Cin, H, W, dev=dev, seed=1)
@@ -53,10 +66,10 @@ def test_conv2d_matches_torch(dev, B, H, W, Cin, Cout, k, s, p, act):
     ref = F.conv2d(x, w, b, stride=s, padding=p)
     ref = {"gelu": F.gelu, "relu": F.relu, "sigmoid": torch.sigmoid, None: lambda t: t}[act](ref)
     out = ops.conv2d(x.permute(0, 2, 3, 1).contiguous(), pack_conv(w), b, ksize=(k, k), stride=(s, s), pad=(p, p), act=act)
-    close(out.permute(0, 3, 1, 2), ref, 2e-5, "conv2d")
+    close(out.permute(0, 3, 1, 2), ref, GEMM_TOL[gemm_mode], "conv2d")
 
 
-def test_conv2d_epilogue_residual_mul_alpha_and_slices(dev):
+def test_conv2d_epilogue_residual_mul_alpha_and_slices(dev, gemm_mode):
     from isr2_amd import ops
     from isr2_amd.prep import pack_conv
     B, H, W, Cin, Cout = 1, 20, 20, 64, 64
@@ -69,11 +82,11 @@ def test_conv2d_epilogue_residual_mul_alpha_and_slices(dev):
     obuf = torch.zeros(B, H, W, 96, device=dev)
     out = ops.conv2d(x, pack_conv(w), b, act="lrelu", res=res, mul=mul, alpha=0.3, out=obuf[..., 16:80])
     ref = res + 0.3 * mul * F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2), w, b), 0.01).permute(0, 2, 3, 1)
-    close(out, ref, 2e-5, "epilogue")
+    close(out, ref, GEMM_TOL[gemm_mode], "epilogue")
     assert obuf[..., :16].abs().max() == 0 and obuf[..., 80:].abs().max() == 0
 
 
-def test_conv2d_pixel_shuffle(dev):
+def test_conv2d_pixel_shuffle(dev, gemm_mode):
     from isr2_amd import ops
     from isr2_amd.prep import pack_conv
     x = rnd(1, 64, 12, 14, dev=dev, seed=9)
@@ -81,16 +94,17 @@ def test_conv2d_pixel_shuffle(dev):
     b = rnd(256, dev=dev, seed=11, scale=0.1)
     ref = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2)
     out = ops.conv2d(x.permute(0, 2, 3, 1).contiguous(), pack_conv(w), b, ksize=(3, 3), pad=(1, 1), shuffle=2)
-    close(out.permute(0, 3, 1, 2), ref, 2e-5, "shuffle")
+    close(out.permute(0, 3, 1, 2), ref, GEMM_TOL[gemm_mode], "shuffle")
 
 
-def test_linear_matches_torch(dev):
+def test_linear_matches_torch(dev, gemm_mode):
     from isr2_amd import ops
     x = rnd(1000, 180, dev=dev, seed=12)
     w = rnd(540, 180, dev=dev, seed=13, scale=0.07)
     b = rnd(540, dev=dev, seed=14, scale=0.1)
-    close(ops.linear(x, w, b), F.linear(x, w, b), 2e-5, "linear")
-    close(ops.linear(x, w, b, act="gelu"), F.gelu(F.linear(x, w, b)), 2e-5, "linear+gelu")
+    close(ops.linear(x, w, b), F.linear(x, w, b), GEMM_TOL[gemm_mode], "linear")
+    close(ops.linear(x, w, b, act="gelu"), F.gelu(F.linear(x, w, b)), GEMM_TOL[gemm_mode], "linear+gelu")
+    close(ops.linear(x, w.clone(), b, dynamic_w=True), F.linear(x, w, b), GEMM_TOL[gemm_mode], "linear dynamic weight")
 
 
 @pytest.mark.parametrize("C,eps", [(180, 1e-5), (64, 1e-6), (360, 1e-5), (1024, 1e-6), (128, 1e-6)])

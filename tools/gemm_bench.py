@@ -19,7 +19,11 @@ SHAPES = [  # name, B,H,W,Cin,Cout,k
 ]
 
 def main():
-    hints = [int(a) for a in sys.argv[1:]] or [0]
+    args = sys.argv[1:]
+    if args and args[0] in ops.GEMM_MODES:
+        ops.set_gemm_mode(args.pop(0))
+    print("mode", ops.gemm_mode())
+    hints = [int(a) for a in args] or [0]
     dev = torch.device("cuda:0")
     for name, B, H, W, Ci, Co, k in SHAPES:
         x = torch.randn(B, H, W, Ci, device=dev)
