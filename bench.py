@@ -60,28 +60,18 @@ def host_threads() -> int:
 
 def broadcast_weights(rank: int, world: int, dev):
     """Rank 0 builds the seeded synthetic state dict; everyone else receives it in ONE RCCL broadcast."""
+    from isr2_amd.parallel import broadcast_state_dict
     from isr2_amd.weights import param_spec, synth_state_dict
-    spec = param_spec()
-    sizes = [int(np.prod(s)) if len(s) else 1 for _, s, _ in spec]
-    total = sum(sizes)
     if world == 1:
         return synth_state_dict(SEED), 0.0
     import torch.distributed as dist
-    flat = torch.empty(total, device=dev, dtype=torch.float32)
-    if rank == 0:
-        sd = synth_state_dict(SEED)
-        flat.copy_(torch.cat([sd[n].reshape(-1) for n, _, _ in spec]))
+    src = synth_state_dict(SEED) if rank == 0 else None
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    dist.broadcast(flat, src=0)
+    sd = broadcast_state_dict(src, param_spec(), rank, world, dev)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out, off = {}, 0
-    for (n, s, _), k in zip(spec, sizes):
-        out[n] = flat[off:off + k].reshape(s)
-        off += k
-    return out, dt
+    return sd, time.perf_counter() - t0
 
 
 def cpu_baseline(sd, threads: int):
