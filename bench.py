@@ -24,7 +24,8 @@ sys.path.insert(0, ROOT)
 TILE = 256
 FLOP_PER_TILE = 11295.4e9          # algorithmic 2xMAC FLOPs of one 256x256 LR tile [measured on the reference]
 MPIX_PER_TILE = (4 * TILE) ** 2 / 1e6
-PEAK_F32_MATRIX_TF = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "bf16x2": 2500.0, "bf16x3": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+MFMA_PER_ALGO_FLOP = {"f32": 1, "bf16": 1, "bf16x2": 2, "bf16x3": 3}
 SEED = 1234
 
 
@@ -180,8 +181,21 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- per-kernel-class accounting: one extra eager pass with HIP events around every launch ---------------
-    roof, breakdown = None, None
+    roof, breakdown, stages = None, None, None
     if rank == 0:
+        def _timed(fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return r, e0.elapsed_time(e1)
+        hat_o, t_hat = _timed(lambda: model.hat.forward(lr))
+        dat_o, t_dat = _timed(lambda: model.dat.forward(lr))
+        naf_o, t_naf = _timed(lambda: model.nafnet.forward(lr))
+        _, t_fus = _timed(lambda: model.fusion.forward(lr, {"hat": hat_o, "dat": dat_o, "nafnet": naf_o}))
+        stages = {"hat_ms": round(t_hat, 2), "dat_ms": round(t_dat, 2), "nafnet_ms": round(t_naf, 2), "fusion_ms": round(t_fus, 2),
+                  "note": "eager launches (includes Python launch gaps the graph replay does not have)"}
         with ops.profile() as prof:
             model(lr)
         agg = {}
@@ -191,9 +205,18 @@ def main():
         mf = [agg.get(k, [0, 0.0, 0.0, 0.0]) for k in ("conv2d", "linear")]
         n_l, ms_l, fl_l = mf[0][0] + mf[1][0], mf[0][1] + mf[1][1], mf[0][2] + mf[1][2]
         achieved = fl_l / (ms_l * 1e-3) / 1e12 if ms_l > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (ff_conv2d: every Linear / Conv2d of the path)",
-                "achieved": achieved, "peak": PEAK_F32_MATRIX_TF, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TF,
-                "traffic": None, "launches_per_tile": n_l, "avg_launch_us": 1e3 * ms_l / max(n_l, 1),
+        mode = ops.gemm_mode()
+        peak = PEAK_TF[mode]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v2.json")
+        if os.path.exists(tpath):                       # PMC counters come from a separate rocprofv3 pass (profiles/)
+            traffic = json.load(open(tpath))["conv_igemm_all_variants"]["hbm_MB_per_launch"] * 1e6
+        roof = {"bound": "mfma", "kernel": "conv_igemm_bf16_kernel / conv_igemm_kernel (ff_conv2d: every Linear / Conv2d of the path)",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": traffic, "traffic_note": "HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r01_pmc_hbm_traffic_v2.json",
+                "algorithmic_bytes_per_launch": 1e6 * (mf[0][3] + mf[1][3]) / max(n_l, 1) / 1e6,
+                "mfma_flops_per_algorithmic_flop": MFMA_PER_ALGO_FLOP[mode], "executed_mfma_frac": achieved * MFMA_PER_ALGO_FLOP[mode] / peak,
+                "launches_per_tile": n_l, "avg_launch_us": 1e3 * ms_l / max(n_l, 1),
                 "algorithmic_gflop_per_launch": fl_l / max(n_l, 1) / 1e9,
                 "share_of_tile_time": ms_l / max(sum(a[1] for a in agg.values()), 1e-9)}
         breakdown = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / max(v[1], 1e-9) / 1e9, 2),
@@ -204,7 +227,7 @@ def main():
         line = {
             "metric": "output MPix/s at x4 SR (256->1024)", "value": value, "unit": "output MPix/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16", "bf16x2": "bf16x2", "bf16x3": "bf16x3 (split bf16 MFMA, fp32 accumulate, fp32-grade results)"}[ops.gemm_mode()], "data": "synthetic",
             "config": {"workload": f"FreqFusion x4 full 3-expert forward (HAT-L + DAT + NAFNet-SR + fusion stack), one "
                                    f"{tile}x{tile} LR tile -> {4 * tile}x{4 * tile} per step per GPU (BASELINE configs[1]); "
                                    "seeded synthetic weights (172.3 M params), 1/f-noise tiles",
@@ -212,7 +235,7 @@ def main():
                        "parallelism": f"tile-sharded x{world}, weights RCCL-broadcast once ({bcast_s * 1e3:.1f} ms), no per-tile collectives",
                        "launch": "hipGraph replay" if graph is not None else "eager"},
             "path_tflops": world * args.steps * flop_per_tile / elapsed / 1e12,
-            "roofline": roof, "kernel_breakdown_ms_per_tile": breakdown,
+            "roofline": roof, "stage_ms_per_tile": stages, "kernel_breakdown_ms_per_tile": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle, 64x64 tile)")

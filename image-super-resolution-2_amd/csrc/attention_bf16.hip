@@ -1,0 +1,253 @@
+// Window attention on the bf16 matrix cores with split operands (same contract as attention.hip /
+// ff_window_attn; selected by ff_window_attn_bf16s).  v_mfma_f32_32x32x16_bf16, fp32 accumulate:
+//   S^T = K Q^T      K tile row-major [key][d] in LDS (80-byte rows: conflict-free ds_read_b128), Q in registers
+//   O^T += V^T P^T   V staged TRANSPOSED [d][key] with the key order inside each 16-key group permuted
+//                    (bits 2 and 3 swapped) so that the 8 keys a lane needs for one k-step are one ds_read_b128
+//                    and line up with the accumulator registers 8s..8s+7 that hold P^T (guide section 3,
+//                    'An accumulator tile as the next MFMA's operand': element j of lane half h is key
+//                    16s + 8(j>>2) + 4h + (j&3)).
+// NTERMS = 3: every product is hi*hi + lo*hi + hi*lo of bf16 splits (fp32-grade); NTERMS = 1: plain bf16.
+// Softmax in base 2: p = exp2(fma(s, log2e, -m*log2e)) -- one v_fma + one v_exp_f32 per element.
+#include "ff_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct AttnBfParams {
+  const float* qkv;
+  float* out;
+  const float* biasT;
+  int ldq, ldo;
+  int q_off, k_off, v_off, o_off;
+  int B, H, W, Hp, Wp;
+  int wh, ww, kh, kw;
+  int sh, sw;
+  int use_mask;
+  int heads, d;
+  float scale;
+  int nwx, nwy;
+};
+
+#define AKC 128            // keys per chunk
+#define KROWB 80           // K row: 32 bf16 + 16 B pad
+#define VROWB 272          // V^T row: 128 bf16 + 16 B pad
+
+__device__ __forceinline__ int swap23(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
+
+template <int NTERMS>
+__global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Kh = smem;                          // [AKC][KROWB]
+  unsigned char* Kl = Kh + AKC * KROWB;
+  unsigned char* Vh = Kl + AKC * KROWB;              // [32][VROWB]
+  unsigned char* Vl = Vh + 32 * VROWB;
+  int* kreg = reinterpret_cast<int*>(Vl + 32 * VROWB);   // [AKC]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int head = bid % p.heads; bid /= p.heads;
+  const int wx = bid % p.nwx; bid /= p.nwx;
+  const int wy = bid % p.nwy;
+  const int b = bid / p.nwy;
+  const int nk = p.kh * p.kw;
+  const int koy = wy * p.wh - (p.kh - p.wh) / 2, kox = wx * p.ww - (p.kw - p.ww) / 2;
+
+  const int qi = wid * 32 + l31;
+  const int qy = wy * p.wh + qi / p.ww, qx = wx * p.ww + qi % p.ww;
+  int oy = qy + p.sh, ox = qx + p.sw;
+  if (oy >= p.Hp) oy -= p.Hp;
+  if (ox >= p.Wp) ox -= p.Wp;
+  const bool qvalid = oy < p.H && ox < p.W;
+  const long long qtok = ((long long)b * p.H + oy) * p.W + ox;
+  int qreg_id = 0;
+  if (p.use_mask) {
+    const int ry = qy < p.Hp - p.wh ? 0 : (qy < p.Hp - p.sh ? 1 : 2);
+    const int rx = qx < p.Wp - p.ww ? 0 : (qx < p.Wp - p.sw ? 1 : 2);
+    qreg_id = 3 * ry + rx;
+  }
+  bf16x8 qh[2], ql[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int dd = 16 * s + 8 * hh + j;
+      const float f = (qvalid && dd < p.d) ? p.qkv[qtok * p.ldq + p.q_off + head * p.d + dd] * p.scale : 0.f;
+      const __bf16 h = (__bf16)f;
+      qh[s][j] = h;
+      ql[s][j] = (__bf16)(f - (float)h);
+    }
+
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float LOG2E = 1.4426950408889634f;
+
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.biasT), 0, p.heads * nk * 256 * 4, 0x00020000);
+  const int nchunks = (nk + AKC - 1) / AKC;
+  for (int c = 0; c < nchunks; ++c) {
+    // ---- stage: 32 lanes = d of one key; K row-major, V transposed with the bit-2/3 key permutation --------
+    // all 16 global loads of a thread are issued before the first LDS write (memory-level parallelism)
+    {
+      float kv[8], vv[8];
+      int rids[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kk = wid * 2 + hh + 16 * i;
+        const int kidx = c * AKC + kk;
+        float kval = 0.f, vval = 0.f;
+        int rid = 0;
+        if (kidx < nk) {
+          const int ky = koy + kidx / p.kw, kx = kox + kidx % p.kw;
+          if (ky >= 0 && kx >= 0 && ky < p.Hp && kx < p.Wp) {
+            int yy = ky + p.sh, xx = kx + p.sw;
+            if (yy >= p.Hp) yy -= p.Hp;
+            if (xx >= p.Wp) xx -= p.Wp;
+            if (yy < p.H && xx < p.W && l31 < p.d) {
+              const long long tok = ((long long)b * p.H + yy) * p.W + xx;
+              kval = p.qkv[tok * p.ldq + p.k_off + head * p.d + l31];
+              vval = p.qkv[tok * p.ldq + p.v_off + head * p.d + l31];
+            }
+            if (p.use_mask) {
+              const int ry = ky < p.Hp - p.wh ? 0 : (ky < p.Hp - p.sh ? 1 : 2);
+              const int rx = kx < p.Wp - p.ww ? 0 : (kx < p.Wp - p.sw ? 1 : 2);
+              rid = 3 * ry + rx;
+            }
+          }
+        }
+        kv[i] = kval; vv[i] = vval; rids[i] = rid;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kk = wid * 2 + hh + 16 * i;
+        const __bf16 k_h = (__bf16)kv[i], v_h = (__bf16)vv[i];
+        *reinterpret_cast<__bf16*>(Kh + kk * KROWB + 2 * l31) = k_h;
+        const int vp = swap23(kk);
+        *reinterpret_cast<__bf16*>(Vh + l31 * VROWB + 2 * vp) = v_h;
+        if (NTERMS == 3) {
+          *reinterpret_cast<__bf16*>(Kl + kk * KROWB + 2 * l31) = (__bf16)(kv[i] - (float)k_h);
+          *reinterpret_cast<__bf16*>(Vl + l31 * VROWB + 2 * vp) = (__bf16)(vv[i] - (float)v_h);
+        }
+        if (l31 == 0) kreg[kk] = rids[i];
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = bias + K Q^T --------------------------------------------------------------------------------
+    f32x16 st[4];
+    {
+      const int cbase = (int)(((long long)head * nk + (long long)c * AKC) * 256 * 4);
+      const int voff = (4 * hh * 256 + qi) * 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kc = t * 32 + (r & 3) + 8 * (r >> 2);
+          const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(brsrc, voff, cbase + kc * 1024, 0);
+          st[t][r] = (c * AKC + kc + 4 * hh < nk) ? __builtin_bit_cast(float, u) : 0.f;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Kh + (t * 32 + l31) * KROWB + 32 * s + 16 * hh);
+        if (NTERMS == 3) {
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(Kl + (t * 32 + l31) * KROWB + 32 * s + 16 * hh);
+          st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[s], st[t], 0, 0, 0);
+          st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[s], st[t], 0, 0, 0);
+        }
+        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[s], st[t], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- mask, running max ---------------------------------------------------------------------------------
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float v = st[t][r];
+        if (p.use_mask && kreg[kk] != qreg_id) v += -100.0f;
+        if (c * AKC + kk >= nk) v = -INFINITY;
+        st[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float corr = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+    const float mneg = -m_new * LOG2E;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= corr;
+    // ---- P = exp2(.), O^T += V^T P^T : accumulator registers 8s..8s+7 of a key tile are the B operand ------
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][8 * s + j], LOG2E, mneg));
+          ls += e;
+          const __bf16 h = (__bf16)e;
+          ph[j] = h;
+          if (NTERMS == 3) pl[j] = (__bf16)(e - (float)h);
+        }
+        const bf16x8 vh = *reinterpret_cast<const bf16x8*>(Vh + l31 * VROWB + 2 * (t * 32 + 16 * s + 8 * hh));
+        if (NTERMS == 3) {
+          const bf16x8 vl = *reinterpret_cast<const bf16x8*>(Vl + l31 * VROWB + 2 * (t * 32 + 16 * s + 8 * hh));
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o, 0, 0, 0);
+        }
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o, 0, 0, 0);
+      }
+    }
+    l_run = l_run * corr + ls;
+    m_run = m_new;
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (qvalid) {
+    float* op = p.out + qtok * p.ldo + p.o_off + head * p.d;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (dd < p.d) op[dd] = o[r] * inv;
+    }
+  }
+}
+
+extern "C" int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_off, int v_off, float* out, int ldo,
+                                    int o_off, const float* biasT, int B, int H, int W, int Hp, int Wp, int wh, int ww,
+                                    int kh, int kw, int shift_h, int shift_w, int use_mask, int heads, int d, float scale,
+                                    int nterms, void* stream) {
+  FF_CHECK_ARG(qkv && out && biasT, "ff_window_attn_bf16s: null pointer");
+  FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_window_attn_bf16s: nterms must be 1 or 3");
+  FF_CHECK_ARG(wh * ww == 256, "ff_window_attn_bf16s: query window must hold 256 tokens (got %dx%d)", wh, ww);
+  FF_CHECK_ARG(d > 0 && d <= 32 && heads > 0, "ff_window_attn_bf16s: head dim %d unsupported (<=32)", d);
+  FF_CHECK_ARG(kh >= wh && kw >= ww && (kh - wh) % 2 == 0 && (kw - ww) % 2 == 0, "ff_window_attn_bf16s: bad key window");
+  FF_CHECK_ARG(Hp % wh == 0 && Wp % ww == 0 && Hp >= H && Wp >= W, "ff_window_attn_bf16s: padded dims must tile by the window");
+  FF_CHECK_ARG(shift_h >= 0 && shift_w >= 0 && shift_h < wh && shift_w < ww, "ff_window_attn_bf16s: bad shift");
+  FF_CHECK_ARG(!(shift_h || shift_w) || (kh == wh && kw == ww), "ff_window_attn_bf16s: shift with overlapping keys unsupported");
+  FF_CHECK_ARG(!use_mask || (shift_h > 0 && shift_w > 0), "ff_window_attn_bf16s: mask needs a shift");
+  AttnBfParams p;
+  p.qkv = qkv; p.out = out; p.biasT = biasT; p.ldq = ldq; p.ldo = ldo;
+  p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.o_off = o_off;
+  p.B = B; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.wh = wh; p.ww = ww; p.kh = kh; p.kw = kw;
+  p.sh = shift_h; p.sw = shift_w; p.use_mask = use_mask; p.heads = heads; p.d = d; p.scale = scale;
+  p.nwx = Wp / ww; p.nwy = Hp / wh;
+  const long long nblk = (long long)B * p.nwx * p.nwy * heads;
+  FF_CHECK_ARG(nblk < (1LL << 31), "ff_window_attn_bf16s: grid too large");
+  const size_t lds = (size_t)2 * AKC * KROWB + (size_t)2 * 32 * VROWB + AKC * 4;
+  if (nterms == 3)
+    hipLaunchKernelGGL(window_attn_bf16_kernel<3>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(window_attn_bf16_kernel<1>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  FF_LAUNCH_CHECK("ff_window_attn_bf16s");
+  return FF_OK;
+}

@@ -12,7 +12,13 @@
 //     workgroup, and stored to LDS as [row][hi k0..31 | lo k0..31] (128 B + 16 B pad = 36 dwords:
 //     36 = 4*9 puts the 16 rows of a ds_read_b128 lane group on 16 distinct 4-bank slots);
 //   - BK = 32: two k-steps of the 32x32x16 MFMA per chunk; a lane's operand is one ds_read_b128
-//     (8 consecutive k of its row) per plane and k-step.
+//     (8 consecutive k of its row) per plane and k-step;
+//   - K is laid out per filter tap with the tap's Cin padded to Cp = ceil32(Cin) when Cin >= 32 ("TAP" mode:
+//     a chunk never straddles taps, so (tap, ci0) are wave-uniform scalars and the per-thread gather needs no
+//     division); small-Cin convolutions (3, 9, 27 ... input channels) keep the flat k = (tap, ci) order;
+//   - tiles: 256x192 with 8 waves (64x96 per wave, 36 MFMAs per chunk and wave) for the 180/360/540/720-wide
+//     transformer layers (65536 tokens -> exactly 256 workgroups per 192 columns: one per CU, no tail),
+//     128x128 / 128x64 / 256x32 with 4 waves elsewhere.
 #include "ff_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -30,6 +36,7 @@ struct ConvBfParams {
   int Ho, Wo, Cout, ldo, ldr;
   int KH, KW, sy, sx, py, px;
   int K, Kp, M;
+  int Cp;          // TAP mode: per-tap padded Cin (multiple of 32); 0 = flat k order
   int act;
   float alpha;
   int shuffle;
@@ -39,11 +46,13 @@ struct ConvBfParams {
 #define BKB 32
 
 template <int BM, int BN, int WM, int WN, bool VEC4, int NTERMS>
-__global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvBfParams p) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16_kernel(ConvBfParams p) {
+  constexpr int NT = WM * WN * 64;                // threads
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
-  constexpr int AQ = BM / 32;                     // A quads (4 k-values) staged per thread: BM*8/256
-  constexpr int BI = (BN * 8 + 255) / 256;        // B 16-byte items staged per thread (hi+lo planes)
+  constexpr int RPP = NT / 8;                     // A rows staged per pass (8 k-quads per row)
+  constexpr int AQ = BM / RPP;                    // A quads (4 k-values) staged per thread
+  constexpr int BI = (BN * 8 + NT - 1) / NT;      // B 16-byte items staged per thread (hi+lo planes)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;                       // [2][BM][ROWB]
   unsigned char* Bs = smem + 2 * BM * ROWB;       // [2][BN][ROWB]
@@ -57,12 +66,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvBfParams p) {
   const int L = ff_xcd_remap(blockIdx.x, mtiles * ntiles);
   const int m0 = (L / ntiles) * BM, n0 = (L % ntiles) * BN;
 
-  const int srow = tid >> 3, kq = tid & 7;        // A staging: row srow + 32*i, k-quad kq
+  const int srow = tid >> 3, kq = tid & 7;        // A staging: row srow + RPP*i, k-quad kq
   int a_b[AQ], a_iy[AQ], a_ix[AQ];
   bool a_ok[AQ];
 #pragma unroll
   for (int i = 0; i < AQ; ++i) {
-    const int m = m0 + srow + 32 * i;
+    const int m = m0 + srow + RPP * i;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
     const int ox = mm % p.Wo, t2 = mm / p.Wo;
@@ -78,14 +87,24 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvBfParams p) {
 
   auto load_chunk = [&](int k0) {
     if (VEC4) {
-      const int k = k0 + 4 * kq;
-      const bool kok = k < p.K;
-      int ky = 0, kx = 0, ci = k;
-      if (!is1x1 && kok) {
-        const int tap = k / p.Cin;
-        ci = k - tap * p.Cin;
+      int ky = 0, kx = 0, ci;
+      bool kok;
+      if (p.Cp > 0) {                               // TAP mode: tap / ci0 are uniform (scalar) per chunk
+        const int tap = k0 / p.Cp;
+        ci = k0 - tap * p.Cp + 4 * kq;
+        kok = ci < p.Cin;
         ky = tap / p.KW;
         kx = tap - ky * p.KW;
+      } else {
+        const int k = k0 + 4 * kq;
+        kok = k < p.K;
+        ci = k;
+        if (!is1x1 && kok) {
+          const int tap = k / p.Cin;
+          ci = k - tap * p.Cin;
+          ky = tap / p.KW;
+          kx = tap - ky * p.KW;
+        }
       }
 #pragma unroll
       for (int i = 0; i < AQ; ++i) {
@@ -119,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvBfParams p) {
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
-      const int id = tid + 256 * j;                // [plane][row][q]
+      const int id = tid + NT * j;                 // [plane][row][q]
       const int plane = id / (BN * 4), rem = id % (BN * 4);
       const int r = rem >> 2, q = rem & 3;
       uint4 v = {0u, 0u, 0u, 0u};
@@ -142,13 +161,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvBfParams p) {
         hi[e] = h;
         lo[e] = (__bf16)(f - (float)h);
       }
-      unsigned char* dst = As + (size_t)(buf * BM + srow + 32 * i) * ROWB + kq * 8;
+      unsigned char* dst = As + (size_t)(buf * BM + srow + RPP * i) * ROWB + kq * 8;
       *reinterpret_cast<bf16x4*>(dst) = hi;
       if (NTERMS >= 2) *reinterpret_cast<bf16x4*>(dst + 64) = lo;
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
-      const int id = tid + 256 * j;
+      const int id = tid + NT * j;
       const int plane = id / (BN * 4), rem = id % (BN * 4);
       const int r = rem >> 2, q = rem & 3;
       if (id < BN * 8 && (NTERMS == 3 || plane == 0))
@@ -236,7 +255,18 @@ template <int BM, int BN, int WM, int WN, int NT>
 static int launch_bf(const ConvBfParams& p, bool vec4, hipStream_t st) {
   const int mt = ff_cdiv(p.M, BM), nt = ff_cdiv(p.Cout, BN);
   const size_t lds = (size_t)2 * (BM + BN) * ROWB;
-  dim3 grid((unsigned)(mt * nt)), block(256);
+  dim3 grid((unsigned)(mt * nt)), block(WM * WN * 64);
+  if (lds > 64 * 1024) {
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[vec4 ? 1 : 0]) {
+      hipError_t e = vec4 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16_kernel<BM, BN, WM, WN, true, NT>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16_kernel<BM, BN, WM, WN, false, NT>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { ff_set_error("ff_conv2d_bf16s: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return FF_ERR_LAUNCH; }
+      attr_set[vec4 ? 1 : 0] = true;
+    }
+  }
   if (vec4)
     hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, true, NT>), grid, block, lds, st, p);
   else
@@ -251,11 +281,12 @@ static int dispatch_bf(const ConvBfParams& p, bool vec4, int cfg, hipStream_t st
     case 1: return launch_bf<128, 128, 2, 2, NT>(p, vec4, st);
     case 2: return launch_bf<128, 64, 2, 2, NT>(p, vec4, st);
     case 3: return launch_bf<256, 32, 4, 1, NT>(p, vec4, st);
+    case 4: return launch_bf<256, 192, 4, 2, NT>(p, vec4, st);
     default: ff_set_error("ff_conv2d_bf16s: bad tile_hint %d", cfg); return FF_ERR_ARG;
   }
 }
 
-extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_lo, int Kp, const float* bias,
+extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_lo, int Kp, int Cp, const float* bias,
                                const float* mul, const float* res, float* out, int B, int H, int W, int Cin, int ldi,
                                int Ho, int Wo, int Cout, int ldo, int ldr, int KH, int KW, int sy, int sx, int py, int px,
                                int act, float alpha, int shuffle, int nterms, int tile_hint, void* stream) {
@@ -265,6 +296,7 @@ extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_
   FF_CHECK_ARG(ldi >= Cin, "ff_conv2d_bf16s: ldi %d < Cin %d", ldi, Cin);
   FF_CHECK_ARG(KH > 0 && KW > 0 && sy > 0 && sx > 0 && py >= 0 && px >= 0, "ff_conv2d_bf16s: bad kernel geometry");
   FF_CHECK_ARG(Kp % 32 == 0 && Kp >= KH * KW * Cin, "ff_conv2d_bf16s: Kp must be K rounded up to 32");
+  FF_CHECK_ARG(Cp == 0 || (Cp % 32 == 0 && Cp >= Cin && Kp == KH * KW * Cp), "ff_conv2d_bf16s: TAP layout needs Kp == taps * Cp, Cp = ceil32(Cin)");
   FF_CHECK_ARG((((uintptr_t)w_hi) & 15) == 0 && (!w_lo || (((uintptr_t)w_lo) & 15) == 0), "ff_conv2d_bf16s: weight planes must be 16-byte aligned");
   FF_CHECK_ARG(shuffle == 0 || shuffle == 2, "ff_conv2d_bf16s: shuffle must be 0 or 2");
   FF_CHECK_ARG(shuffle == 0 || Cout % 4 == 0, "ff_conv2d_bf16s: shuffle needs Cout %% 4 == 0");
@@ -276,15 +308,21 @@ extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.ldi = ldi;
   p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.ldo = ldo; p.ldr = ldr;
   p.KH = KH; p.KW = KW; p.sy = sy; p.sx = sx; p.py = py; p.px = px;
-  p.K = KH * KW * Cin; p.Kp = Kp; p.M = B * Ho * Wo;
+  p.K = KH * KW * Cin; p.Kp = Kp; p.Cp = Cp; p.M = B * Ho * Wo;
   p.act = act; p.alpha = alpha; p.shuffle = shuffle;
   const bool vec4 = (Cin % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)in & 15) == 0);
+  FF_CHECK_ARG(Cp == 0 || vec4, "ff_conv2d_bf16s: TAP layout needs Cin %% 4 == 0 and 16-byte aligned rows");
   hipStream_t st = (hipStream_t)stream;
   int cfg = tile_hint;
   if (cfg <= 0) {
     // measured on MI355X (profiles/r01_gemm_shapes_bf16x3_v2.txt): 128x128 tiles win whenever N pads well or K is long
+    const int r192 = Cout % 192, r128 = Cout % 128;
     if (Cout <= 32) cfg = 3;
-    else if (Cout % 128 == 0 || Cout > 256 || (Cout > 128 && p.K >= 512)) cfg = 1;
+    else if (Cout <= 64) cfg = 2;
+    else if (r128 == 0) cfg = 1;
+    // measured (profiles/r01_gemm_shapes_bf16x3_v3.txt): 256x192 wins for N <= 192 or long K; 128x128 for wide N at K = 180
+    else if (vec4 && p.M >= 256 * 64 && (r192 == 0 || r192 > 128) && (Cout <= 192 || p.K >= 320)) cfg = 4;
+    else if (Cout > 256 || (Cout > 128 && p.K >= 512)) cfg = 1;
     else cfg = 2;
   }
   switch (nterms) {
@@ -294,25 +332,30 @@ extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_
   }
 }
 
-// fp32 [N][K] -> bf16 planes hi/lo [N][Kp] (Kp = K rounded up to 32, zero filled); lo may be NULL
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ w, int N, int K, int Kp, __bf16* __restrict__ hi,
-                                                         __bf16* __restrict__ lo) {
+// fp32 [N][K] -> bf16 planes hi/lo [N][Kp], zero filled; lo may be NULL.
+// Cp == 0: flat, Kp = ceil32(K).  Cp > 0 (TAP layout): K = taps*Cin, column tap*Cp + ci holds w[n][tap*Cin + ci].
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ w, int N, int K, int Kp, int Cin, int Cp,
+                                                         __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
   const long long total = (long long)N * Kp;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int k = (int)(i % Kp);
+    const int kp = (int)(i % Kp);
     const long long n = i / Kp;
-    const float f = k < K ? w[n * K + k] : 0.f;
+    int k = kp;
+    bool ok = kp < K;
+    if (Cp > 0) { const int tap = kp / Cp, ci = kp - tap * Cp; ok = ci < Cin; k = tap * Cin + ci; }
+    const float f = ok ? w[n * K + k] : 0.f;
     const __bf16 h = (__bf16)f;
     hi[i] = h;
     if (lo) lo[i] = (__bf16)(f - (float)h);
   }
 }
 
-extern "C" int ff_split_bf16(const float* w, int N, int K, int Kp, void* hi, void* lo, void* stream) {
+extern "C" int ff_split_bf16(const float* w, int N, int K, int Kp, int Cin, int Cp, void* hi, void* lo, void* stream) {
   FF_CHECK_ARG(w && hi && N > 0 && K > 0 && Kp % 32 == 0 && Kp >= K, "ff_split_bf16: bad args");
+  FF_CHECK_ARG(Cp == 0 || (Cin > 0 && K % Cin == 0 && Cp % 32 == 0 && Cp >= Cin && Kp == (K / Cin) * Cp), "ff_split_bf16: bad TAP layout");
   long long nb = ((long long)N * Kp + 255) / 256;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, N, K, Kp, (__bf16*)hi, (__bf16*)lo);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, N, K, Kp, Cin, Cp, (__bf16*)hi, (__bf16*)lo);
   FF_LAUNCH_CHECK("ff_split_bf16");
   return FF_OK;
 }

@@ -91,18 +91,24 @@ def gemm_mode() -> str:
     return _GEMM_MODE
 
 
-def _split_weight(w: T, dynamic: bool):
-    """bf16 hi/lo planes [N][Kp] of a packed fp32 weight; cached on the tensor object unless `dynamic`."""
+def _split_weight(w: T, dynamic: bool, cin: int):
+    """bf16 hi/lo planes [N][Kp] of a packed fp32 weight [N][taps*cin]; cached on the tensor object unless
+    `dynamic`.  Per-tap padded (TAP) K layout when cin >= 32 and cin % 4 == 0, flat otherwise."""
     nterms = GEMM_MODES[_GEMM_MODE]
     cached = None if dynamic else getattr(w, "_ff_split", None)
-    if cached is not None and cached[3] >= nterms:
+    if cached is not None and cached[4] >= nterms:
         return cached
     N, K = w.shape
-    Kp = (K + 31) // 32 * 32
+    if cin >= 32 and cin % 4 == 0:
+        Cp = (cin + 31) // 32 * 32
+        Kp = (K // cin) * Cp
+    else:
+        Cp, Kp = 0, (K + 31) // 32 * 32
     hi = torch.empty((N, Kp), device=w.device, dtype=torch.bfloat16)
     lo = torch.empty((N, Kp), device=w.device, dtype=torch.bfloat16) if nterms == 3 else None
-    _lib.check(_L().ff_split_bf16(w.data_ptr(), N, K, Kp, hi.data_ptr(), lo.data_ptr() if lo is not None else None, _stream()))
-    ent = (hi, lo, Kp, nterms)
+    _lib.check(_L().ff_split_bf16(w.data_ptr(), N, K, Kp, cin, Cp, hi.data_ptr(), lo.data_ptr() if lo is not None else None,
+                                  _stream()))
+    ent = (hi, lo, Kp, Cp, nterms)
     if not dynamic:
         w._ff_split = ent
     return ent
@@ -177,8 +183,9 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
                                   KH, KW, stride[0], stride[1], pad[0], pad[1], ACT[act], float(alpha), shuffle, tile_hint,
                                   _stream()))
     else:
-        hi, lo, Kp, _ = _split_weight(w, dynamic_w)
-        _lib.check(_L().ff_conv2d_bf16s(xp, hi.data_ptr(), lo.data_ptr() if lo is not None else None, Kp, _ptr(bias), _ptr(mul),
+        aligned = (ldi % 4 == 0) and (xp % 16 == 0)
+        hi, lo, Kp, Cp, _ = _split_weight(w, dynamic_w, Cin if aligned else 0)
+        _lib.check(_L().ff_conv2d_bf16s(xp, hi.data_ptr(), lo.data_ptr() if lo is not None else None, Kp, Cp, _ptr(bias), _ptr(mul),
                                         rp, op, B, H, W, Cin, ldi, Ho, Wo, Cout, ldo, ldr, KH, KW, stride[0], stride[1],
                                         pad[0], pad[1], ACT[act], float(alpha), shuffle, GEMM_MODES[_GEMM_MODE], tile_hint,
                                         _stream()))
@@ -208,8 +215,9 @@ def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] =
         _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, 1, 1, rows, K, ldi, 1, rows, N, ldo, ldr,
                                   1, 1, 1, 1, 0, 0, ACT[act], float(alpha), 0, 0, _stream()))
     else:
-        hi, lo, Kp, _ = _split_weight(w, dynamic_w)
-        _lib.check(_L().ff_conv2d_bf16s(xp, hi.data_ptr(), lo.data_ptr() if lo is not None else None, Kp, _ptr(bias), _ptr(mul),
+        aligned = (ldi % 4 == 0) and (xp % 16 == 0)
+        hi, lo, Kp, Cp, _ = _split_weight(w, dynamic_w, K if aligned else 0)
+        _lib.check(_L().ff_conv2d_bf16s(xp, hi.data_ptr(), lo.data_ptr() if lo is not None else None, Kp, Cp, _ptr(bias), _ptr(mul),
                                         rp, op, 1, 1, rows, K, ldi, 1, rows, N, ldo, ldr, 1, 1, 1, 1, 0, 0, ACT[act],
                                         float(alpha), 0, GEMM_MODES[_GEMM_MODE], 0, _stream()))
     _note(2.0 * rows * N * K, 4.0 * (rows * K + N * K + rows * N * (2 if res is not None else 1)))
@@ -229,9 +237,14 @@ def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int,
     if q_off + heads * d > qkv.shape[-1] or k_off + heads * d > qkv.shape[-1] or v_off + heads * d > qkv.shape[-1] \
             or o_off + heads * d > out.shape[-1]:
         raise _lib.FFError("window_attn: channel offsets out of range")
-    _lib.check(_L().ff_window_attn(qp, ldq, q_off, k_off, v_off, op, ldo, o_off, biasT.data_ptr(), B, H, W, Hp, Wp, win[0],
-                                   win[1], kwin[0], kwin[1], shift[0], shift[1], int(use_mask), heads, d, float(scale),
-                                   _stream()))
+    if _GEMM_MODE == "f32":
+        _lib.check(_L().ff_window_attn(qp, ldq, q_off, k_off, v_off, op, ldo, o_off, biasT.data_ptr(), B, H, W, Hp, Wp, win[0],
+                                       win[1], kwin[0], kwin[1], shift[0], shift[1], int(use_mask), heads, d, float(scale),
+                                       _stream()))
+    else:
+        _lib.check(_L().ff_window_attn_bf16s(qp, ldq, q_off, k_off, v_off, op, ldo, o_off, biasT.data_ptr(), B, H, W, Hp, Wp,
+                                             win[0], win[1], kwin[0], kwin[1], shift[0], shift[1], int(use_mask), heads, d,
+                                             float(scale), 1 if _GEMM_MODE == "bf16" else 3, _stream()))
     nwin = B * (Hp // win[0]) * (Wp // win[1])
     _note(4.0 * nwin * heads * 256 * nk * d, 4.0 * (4.0 * B * H * W * heads * d + heads * nk * 256))
     return out

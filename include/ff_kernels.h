@@ -48,13 +48,14 @@ int ff_conv2d(const float* in, const float* w, const float* bias, const float* m
 /* Same contraction on the bf16 matrix cores with split operands ("bf16x3", csrc/conv_gemm_bf16.hip):
  * a*w ~= a_hi*w_hi + a_lo*w_hi + a_hi*w_lo, every term one v_mfma_f32_32x32x16_bf16 into the same fp32
  * accumulator.  nterms 3 = fp32-grade (~1e-5 rel), 2 = exact activations x bf16 weights, 1 = plain bf16.
- * w_hi / w_lo are bf16 planes [Cout][Kp] (Kp = KH*KW*Cin rounded up to 32, zero filled) made by ff_split_bf16
- * (lo may be NULL for nterms < 3).  Everything else as ff_conv2d. */
-int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_lo, int Kp, const float* bias, const float* mul,
+ * w_hi / w_lo are bf16 planes [Cout][Kp] made by ff_split_bf16 (lo may be NULL for nterms < 3), zero filled, in one of
+ * two K layouts: flat (Cp = 0, Kp = ceil32(KH*KW*Cin)) or per-tap padded (Cp = ceil32(Cin), Kp = KH*KW*Cp; needs
+ * Cin % 4 == 0).  Everything else as ff_conv2d. */
+int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_lo, int Kp, int Cp, const float* bias, const float* mul,
                     const float* res, float* out, int B, int H, int W, int Cin, int ldi, int Ho, int Wo, int Cout,
                     int ldo, int ldr, int KH, int KW, int sy, int sx, int py, int px, int act, float alpha, int shuffle,
                     int nterms, int tile_hint, void* stream);
-int ff_split_bf16(const float* w, int N, int K, int Kp, void* hi, void* lo, void* stream);
+int ff_split_bf16(const float* w, int N, int K, int Kp, int Cin, int Cp, void* hi, void* lo, void* stream);
 
 /* Fused window attention softmax((q*scale) k^T + bias (+mask)) v on fp32 MFMA; one workgroup per
  * (window, head).  qkv is the token tensor [B][H][W][ldq]; q/k/v of head h live at *_off + h*d.
@@ -67,6 +68,12 @@ int ff_split_bf16(const float* w, int N, int K, int Kp, void* hi, void* lo, void
 int ff_window_attn(const float* qkv, int ldq, int q_off, int k_off, int v_off, float* out, int ldo, int o_off,
                    const float* biasT, int B, int H, int W, int Hp, int Wp, int wh, int ww, int kh, int kw,
                    int shift_h, int shift_w, int use_mask, int heads, int d, float scale, void* stream);
+
+/* Same attention on the bf16 matrix cores with split operands (csrc/attention_bf16.hip): nterms 3 = fp32-grade
+ * (hi*hi + lo*hi + hi*lo for both QK^T and PV), 1 = plain bf16 operands.  Same arguments otherwise. */
+int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_off, int v_off, float* out, int ldo, int o_off,
+                         const float* biasT, int B, int H, int W, int Hp, int Wp, int wh, int ww, int kh, int kw,
+                         int shift_h, int shift_w, int use_mask, int heads, int d, float scale, int nterms, void* stream);
 
 /* LayerNorm over the last axis of [rows][C] (nn.LayerNorm and NAFNet LayerNorm2d in NHWC):
  * hat_arch.py:272,307,397,437,964; dat_arch.py:117,734-735,931,1003; nafnet_arch.py:35-41. */

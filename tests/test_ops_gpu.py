@@ -131,7 +131,7 @@ def _hat_bias(table, ws, ows, heads):
 
 
 @pytest.mark.parametrize("H,W,shift", [(32, 48, 0), (32, 48, 8), (16, 16, 8)])
-def test_window_attn_hat(dev, H, W, shift):
+def test_window_attn_hat(dev, gemm_mode, H, W, shift):
     """W-MSA / SW-MSA against the oracle's window attention math evaluated with torch on the GPU."""
     from isr2_amd import ops
     from oracle import freqfusion_oracle as O
@@ -151,10 +151,10 @@ def test_window_attn_hat(dev, H, W, shift):
     o = O._win_merge(o, ws, ws, H, W)
     if shift:
         o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
-    close(out, o, 2e-5, "window_attn")
+    close(out, o, GEMM_TOL[gemm_mode], "window_attn")
 
 
-def test_window_attn_ocab(dev):
+def test_window_attn_ocab(dev, gemm_mode):
     from isr2_amd import ops
     from oracle import freqfusion_oracle as O
     heads, d, ws, ows, C, H, W = 6, 30, 16, 24, 180, 32, 32
@@ -173,11 +173,11 @@ def test_window_attn_ocab(dev):
     kh = kvw[0].reshape(-1, ows * ows, heads, d).transpose(1, 2)
     vh = kvw[1].reshape(-1, ows * ows, heads, d).transpose(1, 2)
     o = O._softmax_attn(qh, kh, vh, bias, None).transpose(1, 2).reshape(-1, ws * ws, C)
-    close(out, O._win_merge(o, ws, ws, H, W), 2e-5, "ocab")
+    close(out, O._win_merge(o, ws, ws, H, W), GEMM_TOL[gemm_mode], "ocab")
 
 
 @pytest.mark.parametrize("H,W,shifted", [(32, 64, False), (48, 48, True), (64, 32, True)])
-def test_window_attn_dat_branches(dev, H, W, shifted):
+def test_window_attn_dat_branches(dev, gemm_mode, H, W, shifted):
     """DAT 8x32 / 32x8 branches on channel halves, zero tokens beyond (H, W), optional shift + mask."""
     from isr2_amd import ops
     from oracle import freqfusion_oracle as O
@@ -203,7 +203,7 @@ def test_window_attn_dat_branches(dev, H, W, shifted):
         o = O._win_merge(o, wh, ww, Hp, Wp)
         if shifted:
             o = torch.roll(o, shifts=(sh, sw), dims=(1, 2))
-        close(out[..., br * half:(br + 1) * half], o[:, :H, :W], 2e-5, f"dat branch {br}")
+        close(out[..., br * half:(br + 1) * half], o[:, :H, :W], GEMM_TOL[gemm_mode], f"dat branch {br}")
 
 
 def test_pool_and_vec_mlp(dev):
