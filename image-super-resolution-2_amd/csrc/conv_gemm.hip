@@ -194,25 +194,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const float mv = (p.mul ? p.mul[n] : 1.f) * p.alpha;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      // indices first, then ALL residual loads, then the stores: `out` may alias `res` as far as the compiler knows,
+      // so a residual load placed after a store is serialised behind it (16 dependent L2 round trips per tile)
+      long long oidx[16];
+      float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wr * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (m >= p.M) continue;
-        float v = ff_act(acc[i][j][r] + bv, p.act) * mv;
-        long long oidx, ridx;
+        const int mm = m < p.M ? m : 0;
+        long long ridx;
         if (p.shuffle == 2) {
-          const int ox = m % p.Wo, t2 = m / p.Wo;
+          const int ox = mm % p.Wo, t2 = mm / p.Wo;
           const int oy = t2 % p.Ho, b = t2 / p.Ho;
           const int co = n >> 2, dy = (n >> 1) & 1, dx = n & 1;
           const long long pix = ((long long)(b * 2 * p.Ho + 2 * oy + dy) * (2 * p.Wo) + 2 * ox + dx);
-          oidx = pix * p.ldo + co;
+          oidx[r] = pix * p.ldo + co;
           ridx = pix * p.ldr + co;
         } else {
-          oidx = (long long)m * p.ldo + n;
-          ridx = (long long)m * p.ldr + n;
+          oidx[r] = (long long)mm * p.ldo + n;
+          ridx = (long long)mm * p.ldr + n;
         }
-        if (p.res) v += p.res[ridx];
-        p.out[oidx] = v;
+        rv[r] = p.res ? p.res[ridx] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m < p.M) p.out[oidx[r]] = ff_act(acc[i][j][r] + bv, p.act) * mv + rv[r];
       }
     }
   }

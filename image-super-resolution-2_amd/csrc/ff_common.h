@@ -45,6 +45,23 @@ __device__ __forceinline__ float ff_act(float v, int act) {
   }
 }
 
+// GELU with the Abramowitz-Stegun 7.1.26 erf (|error| <= 1.5e-7): ~14 VALU ops instead of ~55 for libm erff with its
+// two divergent branches.  Used by the split-bf16 kernels (whose own error is ~1e-5); the f32 parity kernels keep erff.
+__device__ __forceinline__ float ff_gelu_fast(float v) {
+  const float ax = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+  float pl = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  pl = __builtin_fmaf(pl, t, 1.421413741f);
+  pl = __builtin_fmaf(pl, t, -0.284496736f);
+  pl = __builtin_fmaf(pl, t, 0.254829592f);
+  pl *= t;
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  const float er = __builtin_copysignf(1.0f - pl * e, v);
+  return 0.5f * v * (1.0f + er);
+}
+
+__device__ __forceinline__ float ff_act_fast(float v, int act) { return act == ACT_GELU ? ff_gelu_fast(v) : ff_act(v, act); }
+
 static inline int ff_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Bijective XCD-aware block remap (guide section 5 T1): blocks with equal (bid % 8) share an XCD/L2,

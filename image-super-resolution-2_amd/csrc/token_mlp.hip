@@ -1,0 +1,288 @@
+// Fused transformer MLP on tokens:  out = x + fc2( GELU( fc1( LayerNorm(x) ) ) )      (hat_arch.py:83-94,307;
+// the HAB / OCAB feed-forward, 84 per HAT forward).  One launch instead of LayerNorm + 2 GEMMs, and the
+// hidden activation (360 floats per token) never leaves the CU: HBM traffic is x in, out out (94 MB per call at
+// 65 536 tokens instead of 423 MB), which is what bounds these K=180 layers.
+//
+// "Flash-MLP" dataflow, split-operand bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate, bf16x3):
+//   * a wave owns 32 tokens; LayerNorm(x) of those tokens is the B operand of every k-step (lane = token, 8 consecutive
+//     k per lane and step), produced once: the hi halves live in REGISTERS (48 VGPRs), the lo halves in a wave-private
+//     LDS image (keeping both in registers next to the 96 output accumulators overflows the 256-VGPR budget);
+//   * per 32-wide hidden tile:  H^T[hidden][token] = W1 . LN(x)^T  (A = W1 rows from LDS), bias, GELU, split to bf16;
+//     the accumulator has hidden on the registers and the token on the lane, so it IS the B operand of
+//     OUT^T[n][token] += W2[n][hidden] . H^T   (guide section 3, 'An accumulator tile as the next MFMA's operand';
+//     W2's hidden columns are stored in the matching permuted order: bits 2 and 3 of the index swapped);
+//   * weight tiles (W1: 32 x 192, W2: 192 x 32, hi + lo planes) are shared by the 8 waves of the workgroup and filled by
+//     LDS-DMA (global_load_lds_dwordx4: no VGPRs, no staging stores).  The LDS images are 25 + 30 lane-linear 1-KiB
+//     pieces; rows are padded by one 16-byte slot (conflict-free ds_read_b128) and the per-lane SOURCE address does the
+//     row/pad bookkeeping (guide section 5, Caveat).  Two barriers per hidden tile: W1 is refilled for tile t+1 while
+//     GELU + GEMM2 of tile t run, W2 while GEMM1 of tile t+1 runs;
+//   * epilogue: 32x32 tiles are transposed through LDS so global stores / residual loads are 128-byte row segments.
+// Workgroup = 8 waves = 256 tokens: 65 536 tokens -> 256 workgroups = one per CU.
+#include "ff_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define TM_KP 192      // padded K (model dim 180)
+#define TM_NP 192      // padded N
+#define TM_KS 12       // k-steps of 16
+#define W1SLOTS 25     // 16-byte slots per W1 row: 24 data (192 bf16) + 1 pad  -> 400 B
+#define W2SLOTS 5      // slots per W2 row: 4 data (32 bf16) + 1 pad            -> 80 B
+#define W1ROWB (W1SLOTS * 16)
+#define W2ROWB (W2SLOTS * 16)
+#define W1PL (32 * W1SLOTS)          // slots per W1 plane  (800)
+#define W2PL (TM_NP * W2SLOTS)       // slots per W2 plane  (960)
+#define W1PIECES (2 * W1PL / 64)      // 25
+#define W2PIECES (2 * W2PL / 64)      // 30
+#define TILE_ELEMS 6144              // bf16 elements per plane per hidden tile (32*192 == 192*32)
+#define XLROWB 400                   // x_lo image row (per token): 192 bf16 + pad
+
+struct TokenMlpParams {
+  const float* x; float* out;
+  const float* gamma; const float* beta;
+  const __bf16* w;        // [HT][4 planes: W1hi, W1lo, W2hi, W2lo][6144]; W2 planes are [192][32] with permuted hidden columns
+  const float* b1;        // [HT*32] zero padded
+  const float* b2;        // [N]
+  long long M;
+  int ldx, ldo, K, N, HT;
+  float eps;
+};
+
+__global__ __launch_bounds__(512) void token_mlp_kernel(TokenMlpParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int W1B = W1PL * 16, W2B = W2PL * 16;
+  unsigned char* W1s = smem;                         // [2 planes][32][400]
+  unsigned char* W2s = smem + 2 * W1B;               // [2 planes][192][80]
+  unsigned char* XLs = smem + 2 * W1B + 2 * W2B;     // [8 waves][32 tokens][400]
+  float* B1s = reinterpret_cast<float*>(XLs + 8 * 32 * XLROWB);   // [HT*32] fc1 bias (read every hidden tile)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const long long tok = (long long)blockIdx.x * 256 + wid * 32 + l31;
+  const bool tvalid = tok < p.M;
+
+  // ---- LDS-DMA bookkeeping: this wave fills pieces wid, wid+8, ... of each image; per lane the source offset in a tile record
+  int off1[4], off2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int s = (wid + 8 * i) * 64 + lane;               // slot in the W1 image (2 planes x 32 rows x 25 slots)
+    if (s >= 2 * W1PL) s = 2 * W1PL - 1;
+    int plane = s / W1PL, t = s - plane * W1PL, row = t / W1SLOTS, q = t - row * W1SLOTS;
+    if (q > 23) q = 23;
+    off1[i] = plane * TILE_ELEMS + row * 192 + q * 8;
+    s = (wid + 8 * i) * 64 + lane;                   // slot in the W2 image (2 planes x 192 rows x 5 slots)
+    if (s >= 2 * W2PL) s = 2 * W2PL - 1;
+    plane = s / W2PL; t = s - plane * W2PL; row = t / W2SLOTS; q = t - row * W2SLOTS;
+    if (q > 3) q = 3;
+    off2[i] = (2 + plane) * TILE_ELEMS + row * 32 + q * 8;
+  }
+  auto dma_w1 = [&](int ht) {
+    const __bf16* rec = p.w + (long long)ht * (4 * TILE_ELEMS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (wid + 8 * i < W1PIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + off1[i]),
+                                         (__attribute__((address_space(3))) void*)(W1s + (wid + 8 * i) * 1024), 16, 0, 0);
+  };
+  auto dma_w2 = [&](int ht) {
+    const __bf16* rec = p.w + (long long)ht * (4 * TILE_ELEMS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (wid + 8 * i < W2PIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + off2[i]),
+                                         (__attribute__((address_space(3))) void*)(W2s + (wid + 8 * i) * 1024), 16, 0, 0);
+  };
+  dma_w1(0);
+  dma_w2(0);
+  for (int i = tid; i < p.HT * 32; i += 512) B1s[i] = p.b1[i];
+
+  // ---- LayerNorm(x) of this lane's token half -> bf16 hi (registers) / lo (wave-private LDS rows) -----------------
+  bf16x8 xh[TM_KS];
+  unsigned char* xl_row = XLs + (size_t)(wid * 32 + l31) * XLROWB + 16 * hh;     // + 32*st per k-step
+  {
+    float v[TM_KS][8];
+    float s = 0.f;
+    const float* xrow = p.x + (tvalid ? tok : 0) * p.ldx;
+#pragma unroll
+    for (int st = 0; st < TM_KS; ++st) {
+      const int k0 = 16 * st + 8 * hh;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        // branch-free: out-of-range quads re-read quad 0 of a valid token and are zeroed by the select below,
+        // so all 24 loads of the lane are in flight together
+        const bool ok = tvalid && k0 + 4 * q < p.K;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(xrow + (ok ? k0 + 4 * q : 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[st][4 * q + e] = ok ? t[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < TM_KS; ++st)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[st][j];
+    s += __shfl_xor(s, 32);
+    const float mean = s / (float)p.K;
+    float qv = 0.f;
+#pragma unroll
+    for (int st = 0; st < TM_KS; ++st)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 16 * st + 8 * hh + j;
+        const float d = (k < p.K) ? v[st][j] - mean : 0.f;
+        qv += d * d;
+      }
+    qv += __shfl_xor(qv, 32);
+    const float rstd = 1.0f / sqrtf(qv / (float)p.K + p.eps);
+#pragma unroll
+    for (int st = 0; st < TM_KS; ++st) {
+      const int k0 = 16 * st + 8 * hh;
+      const int ka = k0 < p.K ? k0 : 0, kb = k0 + 4 < p.K ? k0 + 4 : 0;     // clamped: values beyond K are unused
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + ka), b0 = *reinterpret_cast<const f32x4*>(p.beta + ka);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.gamma + kb), b1v = *reinterpret_cast<const f32x4*>(p.beta + kb);
+      bf16x8 lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        const float gg = j < 4 ? g0[j & 3] : g1[j & 3], bb = j < 4 ? b0[j & 3] : b1v[j & 3];
+        const float f = (k < p.K) ? (v[st][j] - mean) * rstd * gg + bb : 0.f;
+        const __bf16 h = (__bf16)f;
+        xh[st][j] = h;
+        lo[j] = (__bf16)(f - (float)h);
+      }
+      *reinterpret_cast<bf16x8*>(xl_row + 32 * st) = lo;
+    }
+  }
+
+  f32x16 oacc[6];
+#pragma unroll
+  for (int n = 0; n < 6; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[n][r] = 0.f;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile 0 landed (this wave's pieces)
+  __syncthreads();
+
+  for (int ht = 0; ht < p.HT; ++ht) {
+    // ---- H^T tile = b1 + W1 . LN(x)^T ------------------------------------------------------------------------
+    f32x16 hacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hacc[r] = B1s[ht * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+    {
+      // operands are read TWO k-steps ahead (hipcc otherwise issues ds_read; s_waitcnt lgkmcnt(0); mfma per step and
+      // exposes the LDS latency 24 times per tile); sched_barrier pins the read block in front of the MFMA block
+      const unsigned char* ap = W1s + l31 * W1ROWB + 16 * hh;
+      bf16x8 fa[2], fl[2], fx[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        fa[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u);
+        fl[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u + W1B);
+        fx[u] = *reinterpret_cast<const bf16x8*>(xl_row + 32 * u);
+      }
+#pragma unroll
+      for (int st = 0; st < TM_KS; ++st) {
+        const bf16x8 ah = fa[st & 1], al = fl[st & 1], xl = fx[st & 1];
+        if (st + 2 < TM_KS) {
+          fa[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2));
+          fl[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2) + W1B);
+          fx[st & 1] = *reinterpret_cast<const bf16x8*>(xl_row + 32 * (st + 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], hacc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W2(ht) pieces of this wave have landed
+    __syncthreads();                                    // A: every wave finished reading W1; W2(ht) visible to all
+    if (ht + 1 < p.HT) dma_w1(ht + 1);
+    // ---- GELU, split; registers 8s..8s+7 are the B fragment of k-step s ----------------------------------------
+    bf16x8 gh[2], gl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float g = ff_gelu_fast(hacc[8 * s + j]);
+        const __bf16 h = (__bf16)g;
+        gh[s][j] = h;
+        gl[s][j] = (__bf16)(g - (float)h);
+      }
+    // ---- OUT^T += W2 . H^T ---------------------------------------------------------------------------------------
+    {
+      const unsigned char* ap = W2s + l31 * W2ROWB + 16 * hh;        // step u = 2n + s: row n*32 + l31, k-step s
+      bf16x8 fa[2], fl[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        fa[u] = *reinterpret_cast<const bf16x8*>(ap + (u >> 1) * 32 * W2ROWB + 32 * (u & 1));
+        fl[u] = *reinterpret_cast<const bf16x8*>(ap + (u >> 1) * 32 * W2ROWB + 32 * (u & 1) + W2B);
+      }
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int n = u >> 1, s2 = u & 1;
+        const bf16x8 ah = fa[u & 1], al = fl[u & 1];
+        if (u + 2 < 12) {
+          fa[u & 1] = *reinterpret_cast<const bf16x8*>(ap + ((u + 2) >> 1) * 32 * W2ROWB + 32 * ((u + 2) & 1));
+          fl[u & 1] = *reinterpret_cast<const bf16x8*>(ap + ((u + 2) >> 1) * 32 * W2ROWB + 32 * ((u + 2) & 1) + W2B);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl[s2], oacc[n], 0, 0, 0);
+        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh[s2], oacc[n], 0, 0, 0);
+        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh[s2], oacc[n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W1(ht+1) pieces of this wave have landed
+    __syncthreads();                                    // B: every wave finished reading W2; W1(ht+1) visible to all
+    if (ht + 1 < p.HT) dma_w2(ht + 1);
+  }
+
+  // ---- epilogue: transpose each 32(n) x 32(token) tile through LDS -> coalesced rows; + b2 + residual x ------------
+  float* tr = reinterpret_cast<float*>(smem) + wid * (32 * 33);      // per-wave [token][33] inside the (now idle) W images
+  const long long tok0 = (long long)blockIdx.x * 256 + wid * 32;
+#pragma unroll
+  for (int n = 0; n < 6; ++n) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tr[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * hh] = oacc[n][r];
+    const int col = n * 32 + l31;
+    const bool cok = col < p.N;
+    const float bias = cok ? p.b2[col] : 0.f;
+    // all 16 residual loads are issued before the first store: out may alias x as far as the compiler knows, so a
+    // load placed after a store would be serialised behind it (16 dependent L2 round trips per tile)
+    float rv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long long tk = tok0 + 2 * i + hh;
+      rv[i] = p.x[(tk < p.M ? tk : 0) * p.ldx + (cok ? col : 0)];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = 2 * i + hh;
+      const long long tk = tok0 + t;
+      if (tk < p.M && cok) p.out[tk * p.ldo + col] = tr[t * 33 + l31] + bias + rv[i];
+    }
+  }
+}
+
+extern "C" int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long long M, int K, int hidden_tiles, int N,
+                            const float* gamma, const float* beta, float eps, const void* w_tiles, const float* b1_padded,
+                            const float* b2, void* stream) {
+  FF_CHECK_ARG(x && out && gamma && beta && w_tiles && b1_padded && b2, "ff_token_mlp: null pointer");
+  FF_CHECK_ARG(M > 0 && K > 0 && K <= TM_KP && K % 4 == 0 && N > 0 && N <= TM_NP && hidden_tiles > 0, "ff_token_mlp: needs K, N <= 192 (K %% 4 == 0)");
+  FF_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldo >= N && (((uintptr_t)x) & 15) == 0, "ff_token_mlp: x rows must be 16-byte aligned");
+  FF_CHECK_ARG((((uintptr_t)w_tiles) & 15) == 0 && (((uintptr_t)gamma) & 15) == 0 && (((uintptr_t)beta) & 15) == 0, "ff_token_mlp: weights / gamma / beta must be 16-byte aligned");
+  FF_CHECK_ARG(ldx >= N, "ff_token_mlp: the residual is x itself, so N <= ldx");
+  TokenMlpParams p;
+  p.x = x; p.out = out; p.gamma = gamma; p.beta = beta; p.w = (const __bf16*)w_tiles;
+  p.b1 = b1_padded; p.b2 = b2; p.M = M; p.ldx = ldx; p.ldo = ldo; p.K = K; p.N = N; p.HT = hidden_tiles; p.eps = eps;
+  const size_t lds = (size_t)(2 * W1PL + 2 * W2PL) * 16 + (size_t)8 * 32 * XLROWB + (size_t)hidden_tiles * 32 * 4;
+  FF_CHECK_ARG(lds <= 160 * 1024, "ff_token_mlp: hidden too large for the LDS image");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { ff_set_error("ff_token_mlp: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  const long long nblk = (M + 255) / 256;
+  FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_mlp: grid too large");
+  hipLaunchKernelGGL(token_mlp_kernel, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  FF_LAUNCH_CHECK("ff_token_mlp");
+  return FF_OK;
+}

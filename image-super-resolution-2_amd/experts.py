@@ -13,7 +13,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
-from .prep import pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv
+from .prep import pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv, pack_token_mlp
 
 T = torch.Tensor
 SD = Dict[str, T]
@@ -108,6 +108,10 @@ class HatHIP:
 
     # -- blocks -------------------------------------------------------------------------------
     def _mlp(self, x: T, blk: dict) -> T:
+        if ops.gemm_mode() == "bf16x3":                      # fused LN + fc1 + GELU + fc2 + residual, hidden stays on chip
+            if "mlp_pk" not in blk:
+                blk["mlp_pk"] = pack_token_mlp(blk["fc1"][0], blk["fc1"][1], blk["fc2"][0], blk["fc2"][1])
+            return ops.token_mlp(x, blk["n2"][0], blk["n2"][1], blk["mlp_pk"])
         xn = ops.layernorm(x, *blk["n2"])
         h = ops.linear(xn, *blk["fc1"], act="gelu")
         return ops.linear(h, *blk["fc2"], res=x)

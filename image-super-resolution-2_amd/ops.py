@@ -250,6 +250,18 @@ def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int,
     return out
 
 
+def token_mlp(x: T, gamma: T, beta: T, pk: dict, eps: float = 1e-5) -> T:
+    """x + fc2(GELU(fc1(LayerNorm(x)))) in one launch (bf16x3 only); pk from prep.pack_token_mlp."""
+    xp, ldx, rows, K = rows_view(x, "token_mlp.x")
+    if K != pk["K"] or pk["N"] != K:
+        raise _lib.FFError("token_mlp: shape mismatch")
+    out = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
+    _lib.check(_L().ff_token_mlp(xp, ldx, out.data_ptr(), K, rows, K, pk["ht"], pk["N"], gamma.data_ptr(), beta.data_ptr(),
+                                 float(eps), pk["w"].data_ptr(), pk["b1"].data_ptr(), pk["b2"].data_ptr(), _stream()))
+    _note(4.0 * rows * K * pk["ht"] * 32, 8.0 * rows * K)
+    return out
+
+
 def layernorm(x: T, gamma: T, beta: T, eps: float = 1e-5, out: Optional[T] = None) -> T:
     xp, ldi, rows, C = rows_view(x, "layernorm.x")
     if out is None:
@@ -529,7 +541,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "linear", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
+for _n in ("conv2d", "linear", "token_mlp", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

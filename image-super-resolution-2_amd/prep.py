@@ -34,3 +34,32 @@ def fold_bn_after_conv(w2d: T, b: Optional[T], scale: T, shift: T) -> Tuple[T, T
     w = w2d * scale[:, None]
     bb = shift if b is None else b * scale + shift
     return w.contiguous(), bb.contiguous()
+
+
+def split_bf16(w: T) -> Tuple[T, T]:
+    """fp32 -> (hi, lo) bf16 with hi = rne(w), lo = rne(w - hi): the operand split of the bf16x3 kernels."""
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def pack_token_mlp(w1: T, b1: T, w2: T, b2: T) -> dict:
+    """Weights of ff_token_mlp: fc1 [hidden, K], fc2 [N, hidden] -> padded / tiled / permuted bf16 planes."""
+    hidden, K = w1.shape
+    N = w2.shape[0]
+    assert K <= 192 and N <= 192 and w2.shape[1] == hidden
+    ht = (hidden + 31) // 32
+    dev = w1.device
+    w1p = torch.zeros(ht * 32, 192, device=dev)
+    w1p[:hidden, :K] = w1
+    b1p = torch.zeros(ht * 32, device=dev)
+    b1p[:hidden] = b1
+    w2p = torch.zeros(192, ht * 32, device=dev)
+    w2p[:N, :hidden] = w2
+    pos = torch.arange(32)
+    src = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1)          # stored[pos] = w2[.., swap23(pos)]
+    w2t = w2p.reshape(192, ht, 32)[:, :, src.to(dev)].permute(1, 0, 2).contiguous()   # [ht][192][32]
+    w1h, w1l = split_bf16(w1p.reshape(ht, 32 * 192))
+    w2h, w2l = split_bf16(w2t.reshape(ht, 192 * 32))
+    tiles = torch.stack([w1h, w1l, w2h, w2l], dim=1).contiguous()                     # [ht][4][6144]
+    return dict(ht=ht, K=K, N=N, w=tiles, b1=b1p.contiguous(), b2=b2.contiguous())

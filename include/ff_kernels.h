@@ -75,6 +75,15 @@ int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_off, int v_
                          const float* biasT, int B, int H, int W, int Hp, int Wp, int wh, int ww, int kh, int kw,
                          int shift_h, int shift_w, int use_mask, int heads, int d, float scale, int nterms, void* stream);
 
+/* Fused transformer feed-forward on tokens (csrc/token_mlp.hip): out = x + fc2(GELU(fc1(LayerNorm(x)))), bf16x3 MFMA.
+ * Replaces hat_arch.py:307 (norm2 + Mlp.forward :88-94 + residual) in one launch; the hidden activation stays on chip.
+ * K, N <= 192.  w_tiles: bf16 [hidden_tiles][4][6144] = per 32-wide hidden tile the planes W1_hi, W1_lo ([32][192], zero
+ * padded) and W2_hi, W2_lo ([192][32], hidden column stored at position p = index with bits 2 and 3 swapped)
+ * (prep.pack_token_mlp); b1 zero padded to hidden_tiles*32; gamma/beta/w_tiles 16-byte aligned. */
+int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long long M, int K, int hidden_tiles, int N,
+                 const float* gamma, const float* beta, float eps, const void* w_tiles, const float* b1_padded,
+                 const float* b2, void* stream);
+
 /* LayerNorm over the last axis of [rows][C] (nn.LayerNorm and NAFNet LayerNorm2d in NHWC):
  * hat_arch.py:272,307,397,437,964; dat_arch.py:117,734-735,931,1003; nafnet_arch.py:35-41. */
 int ff_layernorm(const float* in, int ldi, float* out, int ldo, long long rows, int C, const float* gamma,

@@ -107,6 +107,21 @@ def test_linear_matches_torch(dev, gemm_mode):
     close(ops.linear(x, w.clone(), b, dynamic_w=True), F.linear(x, w, b), GEMM_TOL[gemm_mode], "linear dynamic weight")
 
 
+@pytest.mark.parametrize("M", [65536, 1000, 77])
+def test_token_mlp_fused(dev, M):
+    """LN + fc1 + GELU + fc2 + residual in one launch (bf16x3) against the PyTorch fp32 chain."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_token_mlp
+    C, Hd = 180, 360
+    x = rnd(M, C, dev=dev, seed=90, scale=1.5) + 0.3
+    g, b = rnd(C, dev=dev, seed=91) * 0.1 + 1, rnd(C, dev=dev, seed=92) * 0.1
+    w1, b1 = rnd(Hd, C, dev=dev, seed=93, scale=1.0 / math.sqrt(C)), rnd(Hd, dev=dev, seed=94, scale=0.1)
+    w2, b2 = rnd(C, Hd, dev=dev, seed=95, scale=1.0 / math.sqrt(Hd)), rnd(C, dev=dev, seed=96, scale=0.1)
+    ref = x + F.linear(F.gelu(F.linear(F.layer_norm(x, (C,), g, b, 1e-5), w1, b1)), w2, b2)
+    out = ops.token_mlp(x, g, b, pack_token_mlp(w1, b1, w2, b2))
+    close(out, ref, 6e-5, "token_mlp")
+
+
 @pytest.mark.parametrize("C,eps", [(180, 1e-5), (64, 1e-6), (360, 1e-5), (1024, 1e-6), (128, 1e-6)])
 def test_layernorm(dev, C, eps):
     from isr2_amd import ops
