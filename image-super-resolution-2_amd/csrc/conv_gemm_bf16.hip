@@ -219,43 +219,57 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16_kernel(ConvBfPar
     __syncthreads();
   }
 
+  auto epilogue = [&](auto ACTC) {
+    constexpr int ACT = decltype(ACTC)::value;
+    const bool has_res = p.res != nullptr;
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = n0 + wc * TN + j * 32 + l31;
-    if (n >= p.Cout) continue;
-    const float bv = p.bias ? p.bias[n] : 0.f;
-    const float mv = (p.mul ? p.mul[n] : 1.f) * p.alpha;
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wc * TN + j * 32 + l31;
+      if (n >= p.Cout) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+      const float mv = (p.mul ? p.mul[n] : 1.f) * p.alpha;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      // indices first, then ALL residual loads, then the stores: `out` may alias `res` as far as the compiler knows,
-      // so a residual load placed after a store is serialised behind it (16 dependent L2 round trips per tile)
-      long long oidx[16];
-      float rv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int mm = m < p.M ? m : 0;
-        long long ridx;
+      for (int i = 0; i < MI; ++i) {
+        // indices first, then ALL residual loads, then the stores: `out` may alias `res` as far as the compiler knows,
+        // so a residual load placed after a store is serialised behind it (16 dependent L2 round trips per tile)
+        long long oidx[16];
+        float rv[16];
+        const int mb = m0 + wr * TM + i * 32 + 4 * hh;
         if (p.shuffle == 2) {
-          const int ox = mm % p.Wo, t2 = mm / p.Wo;
-          const int oy = t2 % p.Ho, b = t2 / p.Ho;
-          const int co = n >> 2, dy = (n >> 1) & 1, dx = n & 1;
-          const long long pix = ((long long)(b * 2 * p.Ho + 2 * oy + dy) * (2 * p.Wo) + 2 * ox + dx);
-          oidx[r] = pix * p.ldo + co;
-          ridx = pix * p.ldr + co;
-        } else {
-          oidx[r] = (long long)mm * p.ldo + n;
-          ridx = (long long)mm * p.ldr + n;
-        }
-        rv[r] = p.res ? p.res[ridx] : 0.f;
-      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (m < p.M) p.out[oidx[r]] = ff_act_fast(acc[i][j][r] + bv, p.act) * mv + rv[r];
+          for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            const int mm = m < p.M ? m : 0;
+            const int ox = mm % p.Wo, t2 = mm / p.Wo;
+            const int oy = t2 % p.Ho, b = t2 / p.Ho;
+            const int co = n >> 2, dy = (n >> 1) & 1, dx = n & 1;
+            const long long pix = ((long long)(b * 2 * p.Ho + 2 * oy + dy) * (2 * p.Wo) + 2 * ox + dx);
+            oidx[r] = pix * p.ldo + co;
+            rv[r] = has_res ? p.res[pix * p.ldr + co] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            const int mm = m < p.M ? m : 0;
+            oidx[r] = (long long)mm * p.ldo + n;
+            rv[r] = has_res ? p.res[(long long)mm * p.ldr + n] : 0.f;
+          }
+        }
+        if (mb + 28 < p.M) {                      // whole 32-row tile in range: no per-store exec masking
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p.out[oidx[r]] = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            if (m < p.M) p.out[oidx[r]] = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
+          }
+        }
       }
     }
-  }
+  };
+  FF_DISPATCH_ACT(p.act, epilogue)
 }
 
 template <int BM, int BN, int WM, int WN, int NT>

@@ -62,6 +62,57 @@ __device__ __forceinline__ float ff_gelu_fast(float v) {
 
 __device__ __forceinline__ float ff_act_fast(float v, int act) { return act == ACT_GELU ? ff_gelu_fast(v) : ff_act(v, act); }
 
+// compile-time activation (epilogues dispatch ONCE per kernel on the runtime code, not once per element:
+// a per-element switch costs ~10 scalar+vector instructions and a branch for each of the 64-96 outputs of a lane)
+template <int ACT, bool FAST>
+__device__ __forceinline__ float ff_act_c(float v) {
+  if (ACT == ACT_GELU) return FAST ? ff_gelu_fast(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+  if (ACT == ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+  if (ACT == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+template <int V> struct ff_ic { static constexpr int value = V; };
+#define FF_DISPATCH_ACT(act, fn)                 \
+  switch (act) {                                 \
+    case ACT_GELU: fn(ff_ic<ACT_GELU>{}); break;       \
+    case ACT_RELU: fn(ff_ic<ACT_RELU>{}); break;       \
+    case ACT_LRELU: fn(ff_ic<ACT_LRELU>{}); break;     \
+    case ACT_SIGMOID: fn(ff_ic<ACT_SIGMOID>{}); break; \
+    default: fn(ff_ic<ACT_NONE>{}); break;             \
+  }
+
+// A wave reads its 32 token rows (K <= 192 floats each) COALESCED -- four 256-byte row segments per load instruction --
+// and redistributes them through a wave-private LDS patch (32 rows x 68 dwords: 4-bank row shift, conflict-free
+// ds_read_b128) into the MFMA B-operand order: v[st][j] = x[row l31][16 st + 8 hh + j].  Per-lane strided row reads
+// (two lanes per row, 32 B per instruction and row) reach only ~1.7 TB/s; this form streams at the HBM rate.
+#define FF_XS_ROW 68
+__device__ __forceinline__ void ff_wave_rows_to_frags(const float* __restrict__ x, int ldx, long long tok0, long long M, int K,
+                                                      float* xs, int lane, float (&v)[12][8]) {
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int rr = lane >> 4, cq = (lane & 15) * 4;
+#pragma unroll
+  for (int pass = 0; pass < 3; ++pass) {
+    f32x4 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 4 * j + rr, c = 64 * pass + cq;
+      const bool ok = tok0 + r < M && c < K;
+      const f32x4 u = *reinterpret_cast<const f32x4*>(x + (ok ? (tok0 + r) * ldx + c : 0));
+      t[j] = ok ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(xs + (4 * j + rr) * FF_XS_ROW + cq) = t[j];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xs + l31 * FF_XS_ROW + 16 * s4 + 8 * hh);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(xs + l31 * FF_XS_ROW + 16 * s4 + 8 * hh + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[4 * pass + s4][e] = a[e]; v[4 * pass + s4][4 + e] = b[e]; }
+    }
+  }
+}
+
 static inline int ff_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Bijective XCD-aware block remap (guide section 5 T1): blocks with equal (bid % 8) share an XCD/L2,

@@ -1,0 +1,217 @@
+// Token-stationary linear layer for the K <= 192 transformer projections:
+//     out[token][n] = res[token][n] + res2[token][n]*rs2[n] + act( LayerNorm?(x)[token] . W[n] + bias[n] )
+// (hat_arch.py:172 qkv after norm1 :272, :194 proj; dat_arch.py:501,559 qkv/proj, :163 fc1 after norm2 :735).
+// These layers move 140-190 MB for 4-13 GFLOP at 65 536 tokens: they are HBM-bound, and the generic tiled GEMM
+// (conv_gemm_bf16.hip) runs them latency-bound at 1.5 TB/s because K = 180 is only six 32-deep chunks per tile.
+// Here a wave keeps its 32 tokens' (optionally layer-normalised) rows in REGISTERS as split-bf16 MFMA B operands
+// for the whole kernel (x is read from HBM exactly once, LayerNorm costs no extra pass), the weight matrix streams
+// through a two-slot LDS ring by LDS-DMA in 32-row tiles shared by the 8 waves, and every 32(n) x 32(token)
+// accumulator tile is transposed through a wave-private LDS patch so stores are 128-byte row segments.
+// Dataflow per n-tile: OUT^T[n][token] = W_tile . X^T   (A = W rows from LDS, B = X fragments), 36 MFMAs (bf16x3).
+#include "ff_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define TL_KS 12       // k-steps of 16 (K padded to 192)
+#define TL_SLOTS 25    // 16-byte slots per W row: 24 data + 1 pad
+#define TL_ROWB (TL_SLOTS * 16)
+#define TL_PL (32 * TL_SLOTS)            // slots per plane (800)
+#define TL_PIECES (2 * TL_PL / 64)       // 25 one-KiB DMA pieces per tile (hi + lo)
+#define TL_TILE_ELEMS 6144               // bf16 per plane per tile (32 x 192)
+
+struct TokenLinParams {
+  const float* x; float* out;
+  const float* gamma; const float* beta;   // NULL: no LayerNorm
+  const __bf16* w;                         // [NT][2 planes][32][192], rows >= N zero
+  const float* bias;                       // [NT*32] zero padded (or NULL)
+  const float* res; const float* res2; const float* rs2;
+  long long M;
+  int ldx, ldo, ldr, ldr2, K, N, NT, act;
+  float eps;
+};
+
+template <int ACT>
+__global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WB = TL_PL * 16;                     // bytes per plane
+  constexpr int BUFB = 2 * WB;                       // one ring slot (hi + lo)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  float* tr = reinterpret_cast<float*>(smem + 2 * BUFB) + wid * (32 * 33);   // wave-private transpose patch
+  float* xs = reinterpret_cast<float*>(smem + 2 * BUFB + 8 * 32 * 33 * 4) + wid * (32 * FF_XS_ROW);   // wave-private x staging
+  float* Bs = reinterpret_cast<float*>(smem + 2 * BUFB + 8 * 32 * 33 * 4 + 8 * 32 * FF_XS_ROW * 4);   // [NT*32] bias
+  const long long tok0 = (long long)blockIdx.x * 256 + wid * 32;
+  const long long tok = tok0 + l31;
+  const bool tvalid = tok < p.M;
+
+  int off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int s = (wid + 8 * i) * 64 + lane;               // slot in the tile image (2 planes x 32 rows x 25 slots)
+    if (s >= 2 * TL_PL) s = 2 * TL_PL - 1;
+    const int plane = s / TL_PL, t = s - plane * TL_PL, row = t / TL_SLOTS;
+    int q = t - row * TL_SLOTS;
+    if (q > 23) q = 23;
+    off[i] = plane * TL_TILE_ELEMS + row * 192 + q * 8;
+  }
+  auto dma = [&](int nt, int buf) {
+    const __bf16* rec = p.w + (long long)nt * (2 * TL_TILE_ELEMS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (wid + 8 * i < TL_PIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + off[i]),
+                                         (__attribute__((address_space(3))) void*)(smem + buf * BUFB + (wid + 8 * i) * 1024), 16, 0, 0);
+  };
+  dma(0, 0);
+  for (int i = tid; i < p.NT * 32; i += 512) Bs[i] = p.bias ? p.bias[i] : 0.f;
+
+  // ---- x rows (+ LayerNorm) -> split bf16 fragments in registers ------------------------------------------------
+  bf16x8 xh[TL_KS], xl[TL_KS];
+  {
+    float v[TL_KS][8];
+    ff_wave_rows_to_frags(p.x, p.ldx, tok0, p.M, p.K, xs, lane, v);
+    float mean = 0.f, rstd = 1.f;
+    if (p.gamma) {
+      float s = 0.f;
+#pragma unroll
+      for (int st = 0; st < TL_KS; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[st][j];
+      s += __shfl_xor(s, 32);
+      mean = s / (float)p.K;
+      float qv = 0.f;
+#pragma unroll
+      for (int st = 0; st < TL_KS; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = (16 * st + 8 * hh + j < p.K) ? v[st][j] - mean : 0.f;
+          qv += d * d;
+        }
+      qv += __shfl_xor(qv, 32);
+      rstd = 1.0f / sqrtf(qv / (float)p.K + p.eps);
+    }
+#pragma unroll
+    for (int st = 0; st < TL_KS; ++st) {
+      const int k0 = 16 * st + 8 * hh;
+      f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (p.gamma) {
+        const int ka = k0 < p.K ? k0 : 0, kb = k0 + 4 < p.K ? k0 + 4 : 0;
+        g0 = *reinterpret_cast<const f32x4*>(p.gamma + ka); b0 = *reinterpret_cast<const f32x4*>(p.beta + ka);
+        g1 = *reinterpret_cast<const f32x4*>(p.gamma + kb); b1 = *reinterpret_cast<const f32x4*>(p.beta + kb);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gg = j < 4 ? g0[j & 3] : g1[j & 3], bb = j < 4 ? b0[j & 3] : b1[j & 3];
+        const float f = (k0 + j < p.K) ? (p.gamma ? (v[st][j] - mean) * rstd * gg + bb : v[st][j]) : 0.f;
+        const __bf16 h = (__bf16)f;
+        xh[st][j] = h;
+        xl[st][j] = (__bf16)(f - (float)h);
+      }
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile 0 (this wave's DMA pieces) landed
+  for (int nt = 0; nt < p.NT; ++nt) {
+    const int buf = nt & 1;
+    // raw barrier: every wave has waited for its pieces of tile nt (below, before its previous stores) and is done
+    // reading ring slot buf^1.  No global-memory ordering is needed across it, so outstanding stores stay in flight.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nt + 1 < p.NT) dma(nt + 1, buf ^ 1);
+    // residuals of this tile are fetched now and consumed after the MFMAs
+    const int col = nt * 32 + l31;
+    const bool cok = col < p.N;
+    const int cc = cok ? col : 0;
+    float rv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long long tk = tok0 + 2 * i + hh;
+      const long long tq = tk < p.M ? tk : 0;
+      float r0 = p.res ? p.res[tq * p.ldr + cc] : 0.f;
+      if (p.res2) r0 += p.res2[tq * p.ldr2 + cc] * p.rs2[cc];
+      rv[i] = r0;
+    }
+    const unsigned char* ap = smem + buf * BUFB + l31 * TL_ROWB + 16 * hh;
+    f32x16 acc;
+    {
+      const int nb = nt * 32 + 4 * hh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = Bs[nb + (r & 3) + 8 * (r >> 2)];
+    }
+    bf16x8 fa[2], fl[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      fa[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u);
+      fl[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u + WB);
+    }
+#pragma unroll
+    for (int st = 0; st < TL_KS; ++st) {
+      const bf16x8 ah = fa[st & 1], al = fl[st & 1];
+      if (st + 2 < TL_KS) {
+        fa[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2));
+        fl[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2) + WB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[st], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue of this tile: act, transpose through the wave's LDS patch, coalesced row-segment stores --------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tr[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * hh] = ff_act_c<ACT, true>(acc[r]);
+    // One wait per tile, placed BEFORE this tile's stores: it retires the DMA of tile nt+1 (issued a whole tile ago),
+    // this tile's residual loads and the PREVIOUS tile's stores -- so stores always have a full tile to drain
+    // (vmcnt counts stores too; waiting right after issuing them would serialise the kernel on HBM write latency).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float ov[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ov[i] = tr[(2 * i + hh) * 33 + l31] + rv[i];      // 16 LDS reads back to back
+    if (cok) {                                                                        // one exec mask for the whole tile
+      float* op = p.out + (tok0 + hh) * p.ldo + col;
+      if (tok0 + 32 <= p.M) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) op[(long long)(2 * i) * p.ldo] = ov[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (tok0 + 2 * i + hh < p.M) op[(long long)(2 * i) * p.ldo] = ov[i];
+      }
+    }
+  }
+}
+
+extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, int K, int N, int n_tiles,
+                               const float* gamma, const float* beta, float eps, const void* w_tiles,
+                               const float* bias_padded, int act, const float* res, int ldr, const float* res2, int ldr2,
+                               const float* res2_scale, void* stream) {
+  FF_CHECK_ARG(x && out && w_tiles, "ff_token_linear: null pointer");
+  FF_CHECK_ARG(M > 0 && K > 0 && K <= 192 && K % 4 == 0 && N > 0 && n_tiles * 32 >= N, "ff_token_linear: needs K <= 192 (K %% 4 == 0), n_tiles*32 >= N");
+  FF_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldo >= N && (((uintptr_t)x) & 15) == 0, "ff_token_linear: x rows must be 16-byte aligned");
+  FF_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "ff_token_linear: gamma/beta come together");
+  FF_CHECK_ARG((((uintptr_t)w_tiles) & 15) == 0 && (!gamma || ((((uintptr_t)gamma) & 15) == 0 && (((uintptr_t)beta) & 15) == 0)), "ff_token_linear: weights / gamma / beta must be 16-byte aligned");
+  FF_CHECK_ARG(!res || ldr >= N, "ff_token_linear: ldr too small");
+  FF_CHECK_ARG(!res2 || (ldr2 >= N && res2_scale), "ff_token_linear: res2 needs ldr2 >= N and a scale vector");
+  TokenLinParams p;
+  p.x = x; p.out = out; p.gamma = gamma; p.beta = beta; p.w = (const __bf16*)w_tiles; p.bias = bias_padded;
+  p.res = res; p.res2 = res2; p.rs2 = res2_scale; p.M = M; p.ldx = ldx; p.ldo = ldo; p.ldr = ldr; p.ldr2 = ldr2;
+  p.K = K; p.N = N; p.NT = n_tiles; p.act = act; p.eps = eps;
+  const size_t lds = (size_t)2 * 2 * TL_PL * 16 + (size_t)8 * 32 * 33 * 4 + (size_t)8 * 32 * FF_XS_ROW * 4 + (size_t)n_tiles * 32 * 4;
+  FF_CHECK_ARG(lds <= 160 * 1024, "ff_token_linear: N too large for the LDS image");
+  FF_CHECK_ARG(act == ACT_NONE || act == ACT_GELU, "ff_token_linear: act must be none or gelu");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<ACT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { ff_set_error("ff_token_linear: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  const long long nblk = (M + 255) / 256;
+  FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_linear: grid too large");
+  if (act == ACT_GELU)
+    hipLaunchKernelGGL(token_linear_kernel<ACT_GELU>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(token_linear_kernel<ACT_NONE>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  FF_LAUNCH_CHECK("ff_token_linear");
+  return FF_OK;
+}

@@ -100,20 +100,9 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(TokenMlpParams p) {
   {
     float v[TM_KS][8];
     float s = 0.f;
-    const float* xrow = p.x + (tvalid ? tok : 0) * p.ldx;
-#pragma unroll
-    for (int st = 0; st < TM_KS; ++st) {
-      const int k0 = 16 * st + 8 * hh;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        // branch-free: out-of-range quads re-read quad 0 of a valid token and are zeroed by the select below,
-        // so all 24 loads of the lane are in flight together
-        const bool ok = tvalid && k0 + 4 * q < p.K;
-        const f32x4 t = *reinterpret_cast<const f32x4*>(xrow + (ok ? k0 + 4 * q : 0));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[st][4 * q + e] = ok ? t[e] : 0.f;
-      }
-    }
+    // staging patch = this wave's own x_lo rows (12.8 KB, written only below, after the fragments are in registers)
+    ff_wave_rows_to_frags(p.x, p.ldx, (long long)blockIdx.x * 256 + wid * 32, p.M, p.K,
+                          reinterpret_cast<float*>(XLs + (size_t)wid * 32 * XLROWB), lane, v);
 #pragma unroll
     for (int st = 0; st < TM_KS; ++st)
 #pragma unroll
@@ -234,29 +223,41 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(TokenMlpParams p) {
     if (ht + 1 < p.HT) dma_w2(ht + 1);
   }
 
-  // ---- epilogue: transpose each 32(n) x 32(token) tile through LDS -> coalesced rows; + b2 + residual x ------------
+  // ---- epilogue: all 96 residual loads first (x fragments are dead, registers are free), then per n-tile a
+  // transpose through LDS -> coalesced 128-byte row segments.  (out may alias x as far as the compiler knows: a
+  // load placed after a store would be serialised behind it.)
   float* tr = reinterpret_cast<float*>(smem) + wid * (32 * 33);      // per-wave [token][33] inside the (now idle) W images
   const long long tok0 = (long long)blockIdx.x * 256 + wid * 32;
+  float rv[6][16];
+#pragma unroll
+  for (int n = 0; n < 6; ++n) {
+    const int col = n * 32 + l31;
+    const int cc = col < p.N ? col : 0;
+    const float bias = col < p.N ? p.b2[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long long tk = tok0 + 2 * i + hh;
+      rv[n][i] = p.x[(tk < p.M ? tk : 0) * p.ldx + cc] + bias;
+    }
+  }
 #pragma unroll
   for (int n = 0; n < 6; ++n) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) tr[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * hh] = oacc[n][r];
     const int col = n * 32 + l31;
-    const bool cok = col < p.N;
-    const float bias = cok ? p.b2[col] : 0.f;
-    // all 16 residual loads are issued before the first store: out may alias x as far as the compiler knows, so a
-    // load placed after a store would be serialised behind it (16 dependent L2 round trips per tile)
-    float rv[16];
+    float ov[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const long long tk = tok0 + 2 * i + hh;
-      rv[i] = p.x[(tk < p.M ? tk : 0) * p.ldx + (cok ? col : 0)];
-    }
+    for (int i = 0; i < 16; ++i) ov[i] = tr[(2 * i + hh) * 33 + l31] + rv[n][i];
+    if (col < p.N) {
+      float* op = p.out + (tok0 + hh) * p.ldo + col;
+      if (tok0 + 32 <= p.M) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int t = 2 * i + hh;
-      const long long tk = tok0 + t;
-      if (tk < p.M && cok) p.out[tk * p.ldo + col] = tr[t * 33 + l31] + bias + rv[i];
+        for (int i = 0; i < 16; ++i) op[(long long)(2 * i) * p.ldo] = ov[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (tok0 + 2 * i + hh < p.M) op[(long long)(2 * i) * p.ldo] = ov[i];
+      }
     }
   }
 }

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
-from .prep import pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv, pack_token_mlp
+from .prep import pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv, pack_token_mlp, pack_token_linear
 
 T = torch.Tensor
 SD = Dict[str, T]
@@ -39,6 +39,19 @@ class _Weights:
     def opt(self, name: str) -> Optional[T]:
         k = self.p + name
         return self.sd[k].to(self.dev, torch.float32).contiguous() if k in self.sd else None
+
+
+def _tl(blk: dict, key: str) -> dict:
+    """Lazily packed ff_token_linear weights of blk[key] = (W [N,K], b)."""
+    pk = blk.get(key + "_tl")
+    if pk is None:
+        pk = blk[key + "_tl"] = pack_token_linear(blk[key][0], blk[key][1])
+    return pk
+
+
+def _fast() -> bool:
+    """The token-stationary fused kernels exist for the default split-bf16 contraction only."""
+    return ops.gemm_mode() == "bf16x3"
 
 
 # =============================================================================================== HAT
@@ -119,8 +132,8 @@ class HatHIP:
     def hab(self, x: T, blk: dict) -> T:
         _, H, W, C = x.shape
         d = C // self.heads
-        xn = ops.layernorm(x, *blk["n1"])
-        qkv = ops.linear(xn, *blk["qkv"])
+        xn = ops.layernorm(x, *blk["n1"])                          # also feeds the conv branch, so it is materialised
+        qkv = ops.token_linear(xn, _tl(blk, "qkv")) if _fast() else ops.linear(xn, *blk["qkv"])
         att = torch.empty_like(x)
         s = blk["shift"]
         ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
@@ -128,19 +141,24 @@ class HatHIP:
         c1 = ops.conv2d(xn, *blk["cab0"], ksize=(3, 3), pad=(1, 1), act="gelu")
         c2 = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1))
         gate = ops.vec_mlp(ops.pool_mean(c2), *blk["ca1"], "relu", *blk["ca2"], "sigmoid", post=self.conv_scale)
-        t = ops.mix2(x, c2, cb=gate)                               # shortcut + conv_x * conv_scale
-        x = ops.linear(att, *blk["proj"], res=t)                   # + proj(attention)
+        if _fast():                                                # shortcut + conv_x*conv_scale + proj(attention), one launch
+            x = ops.token_linear(att, _tl(blk, "proj"), res=x, res2=c2, res2_scale=gate.reshape(-1))
+        else:
+            t = ops.mix2(x, c2, cb=gate)
+            x = ops.linear(att, *blk["proj"], res=t)
         return self._mlp(x, blk)
 
     def ocab_block(self, x: T, blk: dict) -> T:
         _, H, W, C = x.shape
         d = C // self.heads
-        xn = ops.layernorm(x, *blk["n1"])
-        qkv = ops.linear(xn, *blk["qkv"])
+        if _fast():
+            qkv = ops.token_linear(x, _tl(blk, "qkv"), gamma=blk["n1"][0], beta=blk["n1"][1])      # LayerNorm fused
+        else:
+            qkv = ops.linear(ops.layernorm(x, *blk["n1"]), *blk["qkv"])
         att = torch.empty_like(x)
         ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
                         kwin=(self.ows, self.ows), shift=(0, 0), use_mask=False, heads=self.heads, d=d, scale=d ** -0.5)
-        x = ops.linear(att, *blk["proj"], res=x)
+        x = ops.token_linear(att, _tl(blk, "proj"), res=x) if _fast() else ops.linear(att, *blk["proj"], res=x)
         return self._mlp(x, blk)
 
     def group(self, x: T, g: int) -> T:
@@ -260,8 +278,10 @@ class DatHIP:
         _, H, W, C = x.shape
         half, hh = C // 2, self.heads // 2
         d = half // hh
-        xn = ops.layernorm(x, *blk["n1"])
-        qkv = ops.linear(xn, *blk["qkv"])                                        # [1,H,W,3C] = q | k | v
+        if _fast():
+            qkv = ops.token_linear(x, _tl(blk, "qkv"), gamma=blk["n1"][0], beta=blk["n1"][1])   # LayerNorm fused
+        else:
+            qkv = ops.linear(ops.layernorm(x, *blk["n1"]), *blk["qkv"])          # [1,H,W,3C] = q | k | v
         v = qkv[..., 2 * C:]
         conv_x = ops.dwconv2d(v, blk["dw"][0], blk["dw"][1], post_scale=blk["dw"][2], post_shift=blk["dw"][3], act="gelu")
         if blk["spatial"]:
@@ -285,10 +305,12 @@ class DatHIP:
             fused = ops.mix2(att, conv_x, ca=cm, pb=sm)
         else:
             fused = ops.mix2(att, conv_x, pa=sm, cb=cm)
-        x = ops.linear(fused, *blk["proj"], res=x)
+        x = ops.token_linear(fused, _tl(blk, "proj"), res=x) if _fast() else ops.linear(fused, *blk["proj"], res=x)
         # SGFN
-        xn = ops.layernorm(x, *blk["n2"])
-        y = ops.linear(xn, *blk["fc1"], act="gelu")
+        if _fast():
+            y = ops.token_linear(x, _tl(blk, "fc1"), gamma=blk["n2"][0], beta=blk["n2"][1], act="gelu")
+        else:
+            y = ops.linear(ops.layernorm(x, *blk["n2"]), *blk["fc1"], act="gelu")
         c2 = y.shape[-1] // 2
         gte = ops.layernorm(y[..., c2:], *blk["sgn"])
         gte = ops.dwconv2d(gte, *blk["sgc"])

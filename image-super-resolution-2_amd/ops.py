@@ -262,6 +262,29 @@ def token_mlp(x: T, gamma: T, beta: T, pk: dict, eps: float = 1e-5) -> T:
     return out
 
 
+def token_linear(x: T, pk: dict, *, gamma: Optional[T] = None, beta: Optional[T] = None, eps: float = 1e-5, act=None,
+                 res: Optional[T] = None, res2: Optional[T] = None, res2_scale: Optional[T] = None) -> T:
+    """res + res2*scale + act(LayerNorm?(x) @ W^T + b) for K <= 192 in one launch (bf16x3); pk from prep.pack_token_linear."""
+    xp, ldx, rows, K = rows_view(x, "token_linear.x")
+    if K != pk["K"]:
+        raise _lib.FFError("token_linear: K mismatch")
+    N = pk["N"]
+    out = torch.empty(tuple(x.shape[:-1]) + (N,), device=x.device, dtype=torch.float32)
+    rp, ldr, r2p, ldr2 = None, 0, None, 0
+    if res is not None:
+        rp, ldr, rr, rc = rows_view(res, "token_linear.res")
+        if rr != rows or rc != N:
+            raise _lib.FFError("token_linear: res shape mismatch")
+    if res2 is not None:
+        r2p, ldr2, rr, rc = rows_view(res2, "token_linear.res2")
+        if rr != rows or rc != N or res2_scale is None or res2_scale.numel() != N:
+            raise _lib.FFError("token_linear: res2 shape mismatch")
+    _lib.check(_L().ff_token_linear(xp, ldx, out.data_ptr(), N, rows, K, N, pk["nt"], _ptr(gamma), _ptr(beta), float(eps),
+                                    pk["w"].data_ptr(), _ptr(pk["b"]), ACT[act], rp, ldr, r2p, ldr2, _ptr(res2_scale), _stream()))
+    _note(2.0 * rows * N * K, 4.0 * (rows * K + rows * N * (1 + (res is not None) + (res2 is not None))))
+    return out
+
+
 def layernorm(x: T, gamma: T, beta: T, eps: float = 1e-5, out: Optional[T] = None) -> T:
     xp, ldi, rows, C = rows_view(x, "layernorm.x")
     if out is None:
@@ -541,7 +564,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "linear", "token_mlp", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
+for _n in ("conv2d", "linear", "token_mlp", "token_linear", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

@@ -63,3 +63,18 @@ def pack_token_mlp(w1: T, b1: T, w2: T, b2: T) -> dict:
     w2h, w2l = split_bf16(w2t.reshape(ht, 192 * 32))
     tiles = torch.stack([w1h, w1l, w2h, w2l], dim=1).contiguous()                     # [ht][4][6144]
     return dict(ht=ht, K=K, N=N, w=tiles, b1=b1p.contiguous(), b2=b2.contiguous())
+
+
+def pack_token_linear(w: T, b: Optional[T]) -> dict:
+    """Weights of ff_token_linear: [N, K<=192] -> bf16 [NT][2][32][192] hi/lo tiles, bias padded to NT*32."""
+    N, K = w.shape
+    assert K <= 192
+    nt = (N + 31) // 32
+    wp = torch.zeros(nt * 32, 192, device=w.device)
+    wp[:N, :K] = w
+    hi, lo = split_bf16(wp.reshape(nt, 32 * 192))
+    bp = None
+    if b is not None:
+        bp = torch.zeros(nt * 32, device=w.device)
+        bp[:N] = b
+    return dict(nt=nt, K=K, N=N, w=torch.stack([hi, lo], dim=1).contiguous(), b=bp)

@@ -84,6 +84,17 @@ int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long long M, int 
                  const float* gamma, const float* beta, float eps, const void* w_tiles, const float* b1_padded,
                  const float* b2, void* stream);
 
+/* Token-stationary linear layer for K <= 192 (csrc/token_linear.hip), bf16x3 MFMA:
+ *   out = res + res2*res2_scale[n] + act( LayerNorm?(x) . W^T + bias )        (gamma == NULL: no LayerNorm)
+ * x is read once and kept in registers, W streams through LDS by DMA.  Replaces nn.LayerNorm + nn.Linear (+GELU,
+ * +residuals): hat_arch.py:272+172 (OCAB :397+400), :194+306; dat_arch.py:734+501, :559, :735+163.
+ * w_tiles: bf16 [n_tiles][2][32][192] (hi, lo planes; rows >= N and cols >= K zero) from prep.pack_token_linear;
+ * bias zero padded to n_tiles*32 (or NULL). */
+int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, int K, int N, int n_tiles,
+                    const float* gamma, const float* beta, float eps, const void* w_tiles, const float* bias_padded,
+                    int act, const float* res, int ldr, const float* res2, int ldr2, const float* res2_scale,
+                    void* stream);
+
 /* LayerNorm over the last axis of [rows][C] (nn.LayerNorm and NAFNet LayerNorm2d in NHWC):
  * hat_arch.py:272,307,397,437,964; dat_arch.py:117,734-735,931,1003; nafnet_arch.py:35-41. */
 int ff_layernorm(const float* in, int ldi, float* out, int ldo, long long rows, int C, const float* gamma,

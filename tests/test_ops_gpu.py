@@ -122,6 +122,30 @@ def test_token_mlp_fused(dev, M):
     close(out, ref, 6e-5, "token_mlp")
 
 
+@pytest.mark.parametrize("M,N,ln,act,nres", [(65536, 540, True, None, 0), (1000, 180, False, None, 2), (777, 720, True, "gelu", 0),
+                                            (300, 11, False, "gelu", 0), (256, 180, False, None, 1)])
+def test_token_linear(dev, M, N, ln, act, nres):
+    """Token-stationary linear (+LayerNorm prologue, +GELU, +one or two residuals) against the PyTorch fp32 chain."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_token_linear
+    C = 180
+    x = rnd(M, C, dev=dev, seed=100, scale=1.5) + 0.3
+    g, b = rnd(C, dev=dev, seed=101) * 0.1 + 1, rnd(C, dev=dev, seed=102) * 0.1
+    w, bias = rnd(N, C, dev=dev, seed=103, scale=1.0 / math.sqrt(C)), rnd(N, dev=dev, seed=104, scale=0.1)
+    res, res2, rs2 = rnd(M, N, dev=dev, seed=105), rnd(M, N, dev=dev, seed=106), rnd(N, dev=dev, seed=107)
+    xin = F.layer_norm(x, (C,), g, b, 1e-5) if ln else x
+    ref = F.linear(xin, w, bias)
+    if act == "gelu":
+        ref = F.gelu(ref)
+    if nres >= 1:
+        ref = ref + res
+    if nres == 2:
+        ref = ref + res2 * rs2
+    out = ops.token_linear(x, pack_token_linear(w, bias), gamma=g if ln else None, beta=b if ln else None, act=act,
+                           res=res if nres >= 1 else None, res2=res2 if nres == 2 else None, res2_scale=rs2 if nres == 2 else None)
+    close(out, ref, 6e-5, "token_linear")
+
+
 @pytest.mark.parametrize("C,eps", [(180, 1e-5), (64, 1e-6), (360, 1e-5), (1024, 1e-6), (128, 1e-6)])
 def test_layernorm(dev, C, eps):
     from isr2_amd import ops
