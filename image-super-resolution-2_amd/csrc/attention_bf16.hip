@@ -22,6 +22,7 @@ struct AttnBfParams {
   int wh, ww, kh, kw;
   int sh, sw;
   int use_mask;
+  int nkpad;
   int heads, d;
   float scale;
   int nwx, nwy;
@@ -40,7 +41,8 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
   unsigned char* Kl = Kh + AKC * KROWB;
   unsigned char* Vh = Kl + AKC * KROWB;              // [32][VROWB]
   unsigned char* Vl = Vh + 32 * VROWB;
-  int* kreg = reinterpret_cast<int*>(Vl + 32 * VROWB);   // [AKC]
+  int* ktok = reinterpret_cast<int*>(Vl + 32 * VROWB);   // [nchunks*AKC] token index of every key (or -1: zero key)
+  int* kregAll = ktok + p.nkpad;                         // [nchunks*AKC] shift-region id of every key
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -86,68 +88,85 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
 
   const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.biasT), 0, p.heads * nk * 256 * 4, 0x00020000);
   const int nchunks = (nk + AKC - 1) / AKC;
-  for (int c = 0; c < nchunks; ++c) {
-    // ---- stage: 32 lanes = d of one key; K row-major, V transposed with the bit-2/3 key permutation --------
-    // all 16 global loads of a thread are issued before the first LDS write (memory-level parallelism)
-    {
-      float kv[8], vv[8];
-      int rids[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int kk = wid * 2 + hh + 16 * i;
-        const int kidx = c * AKC + kk;
-        float kval = 0.f, vval = 0.f;
-        int rid = 0;
-        if (kidx < nk) {
-          const int ky = koy + kidx / p.kw, kx = kox + kidx % p.kw;
-          if (ky >= 0 && kx >= 0 && ky < p.Hp && kx < p.Wp) {
-            int yy = ky + p.sh, xx = kx + p.sw;
-            if (yy >= p.Hp) yy -= p.Hp;
-            if (xx >= p.Wp) xx -= p.Wp;
-            if (yy < p.H && xx < p.W && l31 < p.d) {
-              const long long tok = ((long long)b * p.H + yy) * p.W + xx;
-              kval = p.qkv[tok * p.ldq + p.k_off + head * p.d + l31];
-              vval = p.qkv[tok * p.ldq + p.v_off + head * p.d + l31];
-            }
-            if (p.use_mask) {
-              const int ry = ky < p.Hp - p.wh ? 0 : (ky < p.Hp - p.sh ? 1 : 2);
-              const int rx = kx < p.Wp - p.ww ? 0 : (kx < p.Wp - p.sw ? 1 : 2);
-              rid = 3 * ry + rx;
-            }
-          }
+  // ---- per-block key tables: token index (or -1 for the zero keys outside the image) and mask region of every key ------
+  for (int kidx = tid; kidx < nchunks * AKC; kidx += 512) {
+    int tk = -1, rid = 0;
+    if (kidx < nk) {
+      const int ky = koy + kidx / p.kw, kx = kox + kidx % p.kw;
+      if (ky >= 0 && kx >= 0 && ky < p.Hp && kx < p.Wp) {
+        int yy = ky + p.sh, xx = kx + p.sw;
+        if (yy >= p.Hp) yy -= p.Hp;
+        if (xx >= p.Wp) xx -= p.Wp;
+        if (yy < p.H && xx < p.W) tk = (b * p.H + yy) * p.W + xx;
+        if (p.use_mask) {
+          const int ry = ky < p.Hp - p.wh ? 0 : (ky < p.Hp - p.sh ? 1 : 2);
+          const int rx = kx < p.Wp - p.ww ? 0 : (kx < p.Wp - p.sw ? 1 : 2);
+          rid = 3 * ry + rx;
         }
-        kv[i] = kval; vv[i] = vval; rids[i] = rid;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int kk = wid * 2 + hh + 16 * i;
-        const __bf16 k_h = (__bf16)kv[i], v_h = (__bf16)vv[i];
-        *reinterpret_cast<__bf16*>(Kh + kk * KROWB + 2 * l31) = k_h;
-        const int vp = swap23(kk);
-        *reinterpret_cast<__bf16*>(Vh + l31 * VROWB + 2 * vp) = v_h;
-        if (NTERMS == 3) {
-          *reinterpret_cast<__bf16*>(Kl + kk * KROWB + 2 * l31) = (__bf16)(kv[i] - (float)k_h);
-          *reinterpret_cast<__bf16*>(Vl + l31 * VROWB + 2 * vp) = (__bf16)(vv[i] - (float)v_h);
-        }
-        if (l31 == 0) kreg[kk] = rids[i];
       }
     }
-    __syncthreads();
-
-    // ---- S^T = bias + K Q^T --------------------------------------------------------------------------------
+    ktok[kidx] = tk;
+    kregAll[kidx] = rid;
+  }
+  __syncthreads();
+  // only windows in the last window row / column contain more than one shift region (mask is all zero elsewhere)
+  const bool blk_mask = p.use_mask && (wy == p.nwy - 1 || wx == p.nwx - 1);
+  // K/V rows of chunk c+1 are fetched while chunk c is computed; the bias of chunk c is fetched straight into the
+  // S^T accumulators before the staging barrier -- one exposed L2 latency per chunk instead of three.
+  float kv[8], vv[8];
+  const long long hoff = head * p.d + l31;
+  auto fetch_kv = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tk = ktok[c * AKC + wid * 2 + hh + 16 * i];
+      const bool ok = tk >= 0 && l31 < p.d;
+      const float* src = p.qkv + (long long)(ok ? tk : 0) * p.ldq + hoff;
+      const float a = src[p.k_off], bq = src[p.v_off];
+      kv[i] = ok ? a : 0.f;
+      vv[i] = ok ? bq : 0.f;
+    }
+  };
+  fetch_kv(0);
+  for (int c = 0; c < nchunks; ++c) {
+    const bool full = (c + 1) * AKC <= nk;            // every key of this chunk exists: no per-element tail handling
+    // ---- bias of this chunk -> accumulators (C-in of the QK^T MFMAs) ---------------------------------------------
     f32x16 st[4];
     {
       const int cbase = (int)(((long long)head * nk + (long long)c * AKC) * 256 * 4);
       const int voff = (4 * hh * 256 + qi) * 4;
+      if (full) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kc = t * 32 + (r & 3) + 8 * (r >> 2);
-          const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(brsrc, voff, cbase + kc * 1024, 0);
-          st[t][r] = (c * AKC + kc + 4 * hh < nk) ? __builtin_bit_cast(float, u) : 0.f;
-        }
+          for (int r = 0; r < 16; ++r)
+            st[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, voff, cbase + (t * 32 + (r & 3) + 8 * (r >> 2)) * 1024, 0));
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kc = t * 32 + (r & 3) + 8 * (r >> 2);
+            const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(brsrc, voff, cbase + kc * 1024, 0);
+            st[t][r] = (c * AKC + kc + 4 * hh < nk) ? __builtin_bit_cast(float, u) : 0.f;
+          }
+      }
     }
+    // ---- stage K (row-major) and V (transposed, bit-2/3 key permutation) of this chunk from the prefetched registers
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kk = wid * 2 + hh + 16 * i;
+      const __bf16 k_h = (__bf16)kv[i], v_h = (__bf16)vv[i];
+      *reinterpret_cast<__bf16*>(Kh + kk * KROWB + 2 * l31) = k_h;
+      const int vp = swap23(kk);
+      *reinterpret_cast<__bf16*>(Vh + l31 * VROWB + 2 * vp) = v_h;
+      if (NTERMS == 3) {
+        *reinterpret_cast<__bf16*>(Kl + kk * KROWB + 2 * l31) = (__bf16)(kv[i] - (float)k_h);
+        *reinterpret_cast<__bf16*>(Vl + l31 * VROWB + 2 * vp) = (__bf16)(vv[i] - (float)v_h);
+      }
+    }
+    __syncthreads();
+    if (c + 1 < nchunks) fetch_kv(c + 1);
+
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -164,17 +183,24 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- mask, running max ---------------------------------------------------------------------------------
     float mx = -INFINITY;
+    if (blk_mask) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kregAll[c * AKC + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] != qreg_id) st[t][r] += -100.0f;
+    }
+    if (!full) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (c * AKC + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= nk) st[t][r] = -INFINITY;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kk = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        float v = st[t][r];
-        if (p.use_mask && kreg[kk] != qreg_id) v += -100.0f;
-        if (c * AKC + kk >= nk) v = -INFINITY;
-        st[t][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
     const float corr = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
@@ -241,9 +267,11 @@ extern "C" int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_
   p.B = B; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.wh = wh; p.ww = ww; p.kh = kh; p.kw = kw;
   p.sh = shift_h; p.sw = shift_w; p.use_mask = use_mask; p.heads = heads; p.d = d; p.scale = scale;
   p.nwx = Wp / ww; p.nwy = Hp / wh;
+  p.nkpad = (kh * kw + AKC - 1) / AKC * AKC;
   const long long nblk = (long long)B * p.nwx * p.nwy * heads;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_window_attn_bf16s: grid too large");
-  const size_t lds = (size_t)2 * AKC * KROWB + (size_t)2 * 32 * VROWB + AKC * 4;
+  FF_CHECK_ARG((long long)B * H * W < (1LL << 31), "ff_window_attn_bf16s: too many tokens");
+  const size_t lds = (size_t)2 * AKC * KROWB + (size_t)2 * 32 * VROWB + (size_t)2 * p.nkpad * 4;
   if (nterms == 3)
     hipLaunchKernelGGL(window_attn_bf16_kernel<3>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
   else

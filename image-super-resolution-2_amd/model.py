@@ -27,6 +27,9 @@ class FreqFusionHIP:
             raise _lib.FFError("FreqFusionHIP needs an MI355X (torch device 'cuda'); there is no CPU fallback")
         _lib.load()
         self.dev = dev
+        import os
+        self.multi_stream = os.environ.get("FF_STREAMS", "1") != "0"
+        self._side = None
         with torch.cuda.device(dev):
             self.hat = HatHIP(state_dict, dev)
             self.dat = DatHIP(state_dict, dev)
@@ -34,8 +37,27 @@ class FreqFusionHIP:
             self.fusion = FusionHIP(state_dict, dev)
 
     def experts(self, lr: T, taps: Optional[dict] = None) -> Dict[str, T]:
-        """ExpertEnsemble.forward_all sequential branch (expert_loader.py:768-777)."""
-        return {"hat": self.hat.forward(lr, taps), "dat": self.dat.forward(lr, taps), "nafnet": self.nafnet.forward(lr, taps)}
+        """ExpertEnsemble.forward_all (expert_loader.py:768-777).  The three experts are independent until the fusion
+        stack, so each runs on its own HIP stream (fork/join on the caller's stream; the whole fan-out is captured
+        into the HIP graph): latency-bound kernels of one expert overlap with bandwidth-bound kernels of another."""
+        if not self.multi_stream or taps is not None:
+            return {"hat": self.hat.forward(lr, taps), "dat": self.dat.forward(lr, taps), "nafnet": self.nafnet.forward(lr, taps)}
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+        s1, s2 = self._side
+        s1.wait_stream(main)
+        s2.wait_stream(main)
+        with torch.cuda.stream(s1):
+            dat = self.dat.forward(lr)
+        with torch.cuda.stream(s2):
+            naf = self.nafnet.forward(lr)
+        hat = self.hat.forward(lr)
+        main.wait_stream(s1)
+        main.wait_stream(s2)
+        dat.record_stream(main)
+        naf.record_stream(main)
+        return {"hat": hat, "dat": dat, "nafnet": naf}
 
     @torch.no_grad()
     def forward(self, lr: T, taps: Optional[dict] = None) -> T:
