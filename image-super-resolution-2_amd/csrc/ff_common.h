@@ -87,12 +87,13 @@ template <int V> struct ff_ic { static constexpr int value = V; };
 // ds_read_b128) into the MFMA B-operand order: v[st][j] = x[row l31][16 st + 8 hh + j].  Per-lane strided row reads
 // (two lanes per row, 32 B per instruction and row) reach only ~1.7 TB/s; this form streams at the HBM rate.
 #define FF_XS_ROW 68
+template <int NPASS>
 __device__ __forceinline__ void ff_wave_rows_to_frags(const float* __restrict__ x, int ldx, long long tok0, long long M, int K,
-                                                      float* xs, int lane, float (&v)[12][8]) {
+                                                      float* xs, int lane, float (&v)[4 * NPASS][8]) {
   const int l31 = lane & 31, hh = lane >> 5;
   const int rr = lane >> 4, cq = (lane & 15) * 4;
 #pragma unroll
-  for (int pass = 0; pass < 3; ++pass) {
+  for (int pass = 0; pass < NPASS; ++pass) {
     f32x4 t[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

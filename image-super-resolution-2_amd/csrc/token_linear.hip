@@ -12,12 +12,9 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define TL_KS 12       // k-steps of 16 (K padded to 192)
-#define TL_SLOTS 25    // 16-byte slots per W row: 24 data + 1 pad
-#define TL_ROWB (TL_SLOTS * 16)
-#define TL_PL (32 * TL_SLOTS)            // slots per plane (800)
-#define TL_PIECES (2 * TL_PL / 64)       // 25 one-KiB DMA pieces per tile (hi + lo)
-#define TL_TILE_ELEMS 6144               // bf16 per plane per tile (32 x 192)
+// KS = k-steps of 16 (K padded to 16*KS): 12 for the 180-wide transformers, 4 / 8 for NAFNet's 64 / 128 channels.
+// Per W row: 2*KS data slots of 16 bytes + 1 pad slot; a tile (32 rows, hi + lo planes) is 2*32*(2KS+1)/64 DMA pieces
+// (25 / 17 / 9 -- always integral).
 
 struct TokenLinParams {
   const float* x; float* out;
@@ -30,8 +27,10 @@ struct TokenLinParams {
   float eps;
 };
 
-template <int ACT>
+template <int ACT, int TL_KS>
 __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
+  constexpr int TL_SLOTS = 2 * TL_KS + 1, TL_ROWB = TL_SLOTS * 16, TL_PL = 32 * TL_SLOTS, TL_PIECES = 2 * TL_PL / 64;
+  constexpr int TL_TILE_ELEMS = 32 * 16 * TL_KS, KPAD = 16 * TL_KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WB = TL_PL * 16;                     // bytes per plane
   constexpr int BUFB = 2 * WB;                       // one ring slot (hi + lo)
@@ -51,8 +50,8 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
     if (s >= 2 * TL_PL) s = 2 * TL_PL - 1;
     const int plane = s / TL_PL, t = s - plane * TL_PL, row = t / TL_SLOTS;
     int q = t - row * TL_SLOTS;
-    if (q > 23) q = 23;
-    off[i] = plane * TL_TILE_ELEMS + row * 192 + q * 8;
+    if (q > 2 * TL_KS - 1) q = 2 * TL_KS - 1;
+    off[i] = plane * TL_TILE_ELEMS + row * KPAD + q * 8;
   }
   auto dma = [&](int nt, int buf) {
     const __bf16* rec = p.w + (long long)nt * (2 * TL_TILE_ELEMS);
@@ -69,7 +68,7 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
   bf16x8 xh[TL_KS], xl[TL_KS];
   {
     float v[TL_KS][8];
-    ff_wave_rows_to_frags(p.x, p.ldx, tok0, p.M, p.K, xs, lane, v);
+    ff_wave_rows_to_frags<TL_KS / 4>(p.x, p.ldx, tok0, p.M, p.K, xs, lane, v);
     float mean = 0.f, rstd = 1.f;
     if (p.gamma) {
       float s = 0.f;
@@ -181,12 +180,14 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
   }
 }
 
-extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, int K, int N, int n_tiles,
+extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, int K, int kpad, int N, int n_tiles,
                                const float* gamma, const float* beta, float eps, const void* w_tiles,
                                const float* bias_padded, int act, const float* res, int ldr, const float* res2, int ldr2,
                                const float* res2_scale, void* stream) {
   FF_CHECK_ARG(x && out && w_tiles, "ff_token_linear: null pointer");
   FF_CHECK_ARG(M > 0 && K > 0 && K <= 192 && K % 4 == 0 && N > 0 && n_tiles * 32 >= N, "ff_token_linear: needs K <= 192 (K %% 4 == 0), n_tiles*32 >= N");
+  FF_CHECK_ARG(kpad == 64 || kpad == 128 || kpad == 192, "ff_token_linear: kpad must be 64, 128 or 192");
+  FF_CHECK_ARG(kpad >= K, "ff_token_linear: kpad < K");
   FF_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldo >= N && (((uintptr_t)x) & 15) == 0, "ff_token_linear: x rows must be 16-byte aligned");
   FF_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "ff_token_linear: gamma/beta come together");
   FF_CHECK_ARG((((uintptr_t)w_tiles) & 15) == 0 && (!gamma || ((((uintptr_t)gamma) & 15) == 0 && (((uintptr_t)beta) & 15) == 0)), "ff_token_linear: weights / gamma / beta must be 16-byte aligned");
@@ -196,22 +197,26 @@ extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, lon
   p.x = x; p.out = out; p.gamma = gamma; p.beta = beta; p.w = (const __bf16*)w_tiles; p.bias = bias_padded;
   p.res = res; p.res2 = res2; p.rs2 = res2_scale; p.M = M; p.ldx = ldx; p.ldo = ldo; p.ldr = ldr; p.ldr2 = ldr2;
   p.K = K; p.N = N; p.NT = n_tiles; p.act = act; p.eps = eps;
-  const size_t lds = (size_t)2 * 2 * TL_PL * 16 + (size_t)8 * 32 * 33 * 4 + (size_t)8 * 32 * FF_XS_ROW * 4 + (size_t)n_tiles * 32 * 4;
+  const int ks = kpad / 16;
+  const size_t lds = (size_t)2 * 2 * 32 * (2 * ks + 1) * 16 + (size_t)8 * 32 * 33 * 4 + (size_t)8 * 32 * FF_XS_ROW * 4 + (size_t)n_tiles * 32 * 4;
   FF_CHECK_ARG(lds <= 160 * 1024, "ff_token_linear: N too large for the LDS image");
   FF_CHECK_ARG(act == ACT_NONE || act == ACT_GELU, "ff_token_linear: act must be none or gelu");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<ACT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { ff_set_error("ff_token_linear: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
-    attr_set = true;
-  }
   const long long nblk = (M + 255) / 256;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_linear: grid too large");
-  if (act == ACT_GELU)
-    hipLaunchKernelGGL(token_linear_kernel<ACT_GELU>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(token_linear_kernel<ACT_NONE>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+#define TL_LAUNCH(A, KSV)                                                                                                   \
+  do {                                                                                                                      \
+    static bool attr_set = false;                                                                                           \
+    if (!attr_set) {                                                                                                        \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<A, KSV>),                       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
+      if (e != hipSuccess) { ff_set_error("ff_token_linear: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; } \
+      attr_set = true;                                                                                                      \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((token_linear_kernel<A, KSV>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);        \
+  } while (0)
+  if (act == ACT_GELU) { if (ks == 4) TL_LAUNCH(ACT_GELU, 4); else if (ks == 8) TL_LAUNCH(ACT_GELU, 8); else TL_LAUNCH(ACT_GELU, 12); }
+  else { if (ks == 4) TL_LAUNCH(ACT_NONE, 4); else if (ks == 8) TL_LAUNCH(ACT_NONE, 8); else TL_LAUNCH(ACT_NONE, 12); }
+#undef TL_LAUNCH
   FF_LAUNCH_CHECK("ff_token_linear");
   return FF_OK;
 }

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(TokenMlpParams p) {
     float v[TM_KS][8];
     float s = 0.f;
     // staging patch = this wave's own x_lo rows (12.8 KB, written only below, after the fragments are in registers)
-    ff_wave_rows_to_frags(p.x, p.ldx, (long long)blockIdx.x * 256 + wid * 32, p.M, p.K,
+    ff_wave_rows_to_frags<3>(p.x, p.ldx, (long long)blockIdx.x * 256 + wid * 32, p.M, p.K,
                           reinterpret_cast<float*>(XLs + (size_t)wid * 32 * XLROWB), lane, v);
 #pragma unroll
     for (int st = 0; st < TM_KS; ++st)

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
-from .prep import pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv, pack_token_mlp, pack_token_linear
+from .prep import pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv, pack_token_mlp, pack_token_linear, pack_naf_ffn
 
 T = torch.Tensor
 SD = Dict[str, T]
@@ -368,13 +368,19 @@ class NafnetHIP:
 
     def block(self, x: T, k: dict) -> T:
         c = x.shape[-1]
-        t = ops.layernorm(x, *k["n1"], eps=1e-6)
-        t = ops.linear(t, *k["c1"])
-        t = ops.dwconv2d(t, *k["c2"])
-        g = ops.fma3(None, t[..., :c], t[..., c:])                          # SimpleGate
-        sca = ops.vec_mlp(ops.pool_mean(g), *k["sca"], None)                # [1,c]
-        w3 = ops.mix2(k["c3"][0], ca=sca.reshape(-1))                       # conv3(g * sca) == (W3 . diag(sca)) g
+        flash = _fast() and c in (64, 128)                                   # HR levels: the bandwidth-bound ones
+        if flash:
+            t = ops.token_linear(x, _tl(k, "c1"), gamma=k["n1"][0], beta=k["n1"][1], eps=1e-6)    # LayerNorm2d + conv1
+        else:
+            t = ops.linear(ops.layernorm(x, *k["n1"], eps=1e-6), *k["c1"])
+        g, pooled = ops.dwconv3_gate_pool(t, *k["c2"])                       # conv2 + SimpleGate + SCA pool sums
+        sca = ops.vec_mlp(pooled, *k["sca"], None)                           # [1,c]
+        w3 = ops.mix2(k["c3"][0], ca=sca.reshape(-1))                        # conv3(g * sca) == (W3 . diag(sca)) g
         y = ops.linear(g, w3, k["c3"][1], res=x, mul=k["beta"], dynamic_w=True)
+        if flash:
+            if "ffn_pk" not in k:
+                k["ffn_pk"] = pack_naf_ffn(k["c4"][0], k["c4"][1], k["c5"][0], k["c5"][1])
+            return ops.naf_ffn(y, k["ffn_pk"], k["n2"][0], k["n2"][1], k["gamma"])
         t = ops.linear(ops.layernorm(y, *k["n2"], eps=1e-6), *k["c4"])
         g = ops.fma3(None, t[..., :c], t[..., c:])
         return ops.linear(g, *k["c5"], res=y, mul=k["gamma"])

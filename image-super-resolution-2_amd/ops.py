@@ -279,9 +279,37 @@ def token_linear(x: T, pk: dict, *, gamma: Optional[T] = None, beta: Optional[T]
         r2p, ldr2, rr, rc = rows_view(res2, "token_linear.res2")
         if rr != rows or rc != N or res2_scale is None or res2_scale.numel() != N:
             raise _lib.FFError("token_linear: res2 shape mismatch")
-    _lib.check(_L().ff_token_linear(xp, ldx, out.data_ptr(), N, rows, K, N, pk["nt"], _ptr(gamma), _ptr(beta), float(eps),
+    _lib.check(_L().ff_token_linear(xp, ldx, out.data_ptr(), N, rows, K, pk["kpad"], N, pk["nt"], _ptr(gamma), _ptr(beta), float(eps),
                                     pk["w"].data_ptr(), _ptr(pk["b"]), ACT[act], rp, ldr, r2p, ldr2, _ptr(res2_scale), _stream()))
     _note(2.0 * rows * N * K, 4.0 * (rows * K + rows * N * (1 + (res is not None) + (res2 is not None))))
+    return out
+
+
+def dwconv3_gate_pool(t: T, w_tap: T, bias: T):
+    """t [1,H,W,2C] -> (dw3x3(t)[..., :C] * dw3x3(t)[..., C:], its per-channel mean [1,C]) in one pass."""
+    tp, ldi, B, H, W, C2 = _nhwc(t, "dwconv3_gate_pool.t")
+    if B != 1 or C2 % 2 or tuple(w_tap.shape) != (9, C2):
+        raise _lib.FFError("dwconv3_gate_pool: expects B == 1, [9, 2C] tap-major weights")
+    C = C2 // 2
+    out = torch.empty((1, H, W, C), device=t.device, dtype=torch.float32)
+    pooled = torch.empty((1, C), device=t.device, dtype=torch.float32)
+    nwork = int(_L().ff_dwconv3_gate_pool_workspace(C))
+    work = torch.empty(nwork, device=t.device, dtype=torch.float32)
+    _lib.check(_L().ff_dwconv3_gate_pool(tp, ldi, out.data_ptr(), C, H, W, C, w_tap.data_ptr(), bias.data_ptr(), pooled.data_ptr(),
+                                         work.data_ptr(), nwork, _stream()))
+    _note(2.0 * H * W * C2 * 9, 4.0 * H * W * (C2 + C))
+    return out, pooled
+
+
+def naf_ffn(y: T, pk: dict, ln_g: T, ln_b: T, out_scale: T, eps: float = 1e-6) -> T:
+    """y + out_scale * conv5(SimpleGate(conv4(LayerNorm(y)))) in one launch (C = 64 / 128, bf16x3)."""
+    yp, ldy, rows, C = rows_view(y, "naf_ffn.y")
+    if C != pk["C"]:
+        raise _lib.FFError("naf_ffn: channel mismatch")
+    out = torch.empty(tuple(y.shape), device=y.device, dtype=torch.float32)
+    _lib.check(_L().ff_naf_ffn(yp, ldy, out.data_ptr(), C, rows, C, ln_g.data_ptr(), ln_b.data_ptr(), float(eps), pk["w"].data_ptr(),
+                               pk["b4"].data_ptr(), pk["b5"].data_ptr(), out_scale.data_ptr(), _stream()))
+    _note(2.0 * rows * C * 3 * C, 8.0 * rows * C)
     return out
 
 
@@ -564,7 +592,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "linear", "token_mlp", "token_linear", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
+for _n in ("conv2d", "linear", "token_mlp", "token_linear", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

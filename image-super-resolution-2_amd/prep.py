@@ -66,15 +66,36 @@ def pack_token_mlp(w1: T, b1: T, w2: T, b2: T) -> dict:
 
 
 def pack_token_linear(w: T, b: Optional[T]) -> dict:
-    """Weights of ff_token_linear: [N, K<=192] -> bf16 [NT][2][32][192] hi/lo tiles, bias padded to NT*32."""
+    """Weights of ff_token_linear: [N, K<=192] -> bf16 [NT][2][32][kpad] hi/lo tiles (kpad = 64/128/192), bias padded."""
     N, K = w.shape
     assert K <= 192
+    kpad = 64 if K <= 64 else (128 if K <= 128 else 192)
     nt = (N + 31) // 32
-    wp = torch.zeros(nt * 32, 192, device=w.device)
+    wp = torch.zeros(nt * 32, kpad, device=w.device)
     wp[:N, :K] = w
-    hi, lo = split_bf16(wp.reshape(nt, 32 * 192))
+    hi, lo = split_bf16(wp.reshape(nt, 32 * kpad))
     bp = None
     if b is not None:
         bp = torch.zeros(nt * 32, device=w.device)
         bp[:N] = b
-    return dict(nt=nt, K=K, N=N, w=torch.stack([hi, lo], dim=1).contiguous(), b=bp)
+    return dict(nt=nt, K=K, kpad=kpad, N=N, w=torch.stack([hi, lo], dim=1).contiguous(), b=bp)
+
+
+def pack_naf_ffn(w4: T, b4: T, w5: T, b5: T) -> dict:
+    """Weights of ff_naf_ffn: conv4 [2C, C], conv5 [C, C] -> per gated 32-channel tile g the record
+    [W4a_hi, W4a_lo, W4b_hi, W4b_lo (32 x C: rows 32g.. and C+32g..), W5_hi, W5_lo (C x 32, columns 32g.. permuted)]."""
+    C = w5.shape[0]
+    assert C in (64, 128) and tuple(w4.shape) == (2 * C, C) and tuple(w5.shape) == (C, C)
+    gt = C // 32
+    pos = torch.arange(32)
+    src = ((pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1)).to(w4.device)
+    recs = []
+    for g in range(gt):
+        a = w4[32 * g:32 * g + 32].reshape(-1)
+        b = w4[C + 32 * g:C + 32 * g + 32].reshape(-1)
+        w5t = w5[:, 32 * g:32 * g + 32][:, src].reshape(-1)
+        ah, al = split_bf16(a)
+        bh, bl = split_bf16(b)
+        wh, wl = split_bf16(w5t)
+        recs.append(torch.cat([ah, al, bh, bl, wh, wl]))
+    return dict(C=C, w=torch.stack(recs).contiguous(), b4=b4.contiguous(), b5=b5.contiguous())

@@ -88,12 +88,25 @@ int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long long M, int 
  *   out = res + res2*res2_scale[n] + act( LayerNorm?(x) . W^T + bias )        (gamma == NULL: no LayerNorm)
  * x is read once and kept in registers, W streams through LDS by DMA.  Replaces nn.LayerNorm + nn.Linear (+GELU,
  * +residuals): hat_arch.py:272+172 (OCAB :397+400), :194+306; dat_arch.py:734+501, :559, :735+163.
- * w_tiles: bf16 [n_tiles][2][32][192] (hi, lo planes; rows >= N and cols >= K zero) from prep.pack_token_linear;
+ * kpad = K rounded up to 64 / 128 / 192.  w_tiles: bf16 [n_tiles][2][32][kpad] (hi, lo planes; rows >= N and cols >= K
+ * zero) from prep.pack_token_linear;
  * bias zero padded to n_tiles*32 (or NULL). */
-int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, int K, int N, int n_tiles,
+int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, int K, int kpad, int N, int n_tiles,
                     const float* gamma, const float* beta, float eps, const void* w_tiles, const float* bias_padded,
                     int act, const float* res, int ldr, const float* res2, int ldr2, const float* res2_scale,
                     void* stream);
+
+/* NAFNet block fusions (csrc/naf_fused.hip).
+ * ff_dwconv3_gate_pool: out[p][c] = dw3x3(in)[p][c] * dw3x3(in)[p][C + c] (conv2 + SimpleGate, nafnet_arch.py:78-81,51-52)
+ *   and pooled[c] = mean_p out[p][c] (the SCA pool, :86) in one pass.  in [H][W][ldi] with 2C channels, weights tap-major
+ *   [9][2C], bias [2C]; work: ff_dwconv3_gate_pool_workspace(C) floats.
+ * ff_naf_ffn: out = y + out_scale[n] * (W5 . SimpleGate(W4 . LayerNorm(y) + b4) + b5)   (nafnet_arch.py:124-131), C = 64 / 128,
+ *   bf16x3 MFMA, hidden activation on chip.  w_tiles from prep.pack_naf_ffn. */
+long long ff_dwconv3_gate_pool_workspace(int C);
+int ff_dwconv3_gate_pool(const float* in, int ldi, float* out, int ldo, int H, int W, int C, const float* w_tapmajor,
+                         const float* bias, float* pooled, float* work, long long work_floats, void* stream);
+int ff_naf_ffn(const float* y, int ldy, float* out, int ldo, long long M, int C, const float* gamma_ln, const float* beta_ln,
+               float eps, const void* w_tiles, const float* b4, const float* b5, const float* out_scale, void* stream);
 
 /* LayerNorm over the last axis of [rows][C] (nn.LayerNorm and NAFNet LayerNorm2d in NHWC):
  * hat_arch.py:272,307,397,437,964; dat_arch.py:117,734-735,931,1003; nafnet_arch.py:35-41. */

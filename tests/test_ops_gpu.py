@@ -146,6 +146,47 @@ def test_token_linear(dev, M, N, ln, act, nres):
     close(out, ref, 6e-5, "token_linear")
 
 
+@pytest.mark.parametrize("C,H,W", [(64, 40, 56), (128, 33, 20), (512, 16, 16), (1024, 8, 8)])
+def test_naf_dwconv_gate_pool(dev, C, H, W):
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_dw
+    t = rnd(1, 2 * C, H, W, dev=dev, seed=110)
+    w, b = rnd(2 * C, 1, 3, 3, dev=dev, seed=111, scale=0.3), rnd(2 * C, dev=dev, seed=112, scale=0.1)
+    d = F.conv2d(t, w, b, padding=1, groups=2 * C)
+    ref = d[:, :C] * d[:, C:]
+    g, pooled = ops.dwconv3_gate_pool(t.permute(0, 2, 3, 1).contiguous(), pack_dw(w), b)
+    close(g.permute(0, 3, 1, 2), ref, 1e-5, "dwconv gate")
+    close(pooled, ref.mean(dim=(2, 3)), 1e-5, "pooled")
+
+
+@pytest.mark.parametrize("C,M", [(64, 65536), (64, 300), (128, 4096), (128, 77)])
+def test_naf_ffn_fused(dev, C, M):
+    """y + gamma * conv5(SimpleGate(conv4(LayerNorm2d(y)))) in one launch against the PyTorch fp32 chain."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_naf_ffn
+    y = rnd(M, C, dev=dev, seed=120, scale=1.3) + 0.2
+    g, b = rnd(C, dev=dev, seed=121) * 0.1 + 1, rnd(C, dev=dev, seed=122) * 0.1
+    w4, b4 = rnd(2 * C, C, dev=dev, seed=123, scale=1.0 / math.sqrt(C)), rnd(2 * C, dev=dev, seed=124, scale=0.1)
+    w5, b5 = rnd(C, C, dev=dev, seed=125, scale=1.0 / math.sqrt(C)), rnd(C, dev=dev, seed=126, scale=0.1)
+    gam = rnd(C, dev=dev, seed=127, scale=0.3)
+    t = F.linear(F.layer_norm(y, (C,), g, b, 1e-6), w4, b4)
+    ref = y + gam * F.linear(t[:, :C] * t[:, C:], w5, b5)
+    out = ops.naf_ffn(y, pack_naf_ffn(w4, b4, w5, b5), g, b, gam)
+    close(out, ref, 6e-5, "naf_ffn")
+
+
+@pytest.mark.parametrize("K,N", [(64, 128), (128, 256)])
+def test_token_linear_small_k(dev, K, N):
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_token_linear
+    M = 5000
+    x = rnd(M, K, dev=dev, seed=130) + 0.1
+    g, b = rnd(K, dev=dev, seed=131) * 0.1 + 1, rnd(K, dev=dev, seed=132) * 0.1
+    w, bias = rnd(N, K, dev=dev, seed=133, scale=1.0 / math.sqrt(K)), rnd(N, dev=dev, seed=134, scale=0.1)
+    ref = F.linear(F.layer_norm(x, (K,), g, b, 1e-6), w, bias)
+    close(ops.token_linear(x, pack_token_linear(w, bias), gamma=g, beta=b, eps=1e-6), ref, 6e-5, "token_linear small K")
+
+
 @pytest.mark.parametrize("C,eps", [(180, 1e-5), (64, 1e-6), (360, 1e-5), (1024, 1e-6), (128, 1e-6)])
 def test_layernorm(dev, C, eps):
     from isr2_amd import ops
