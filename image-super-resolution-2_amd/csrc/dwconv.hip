@@ -5,12 +5,12 @@
 // Channels are the fastest axis, so a wave reads 64 consecutive channels (or 16 float4) of one tap
 // coalesced; the kh*kw taps of neighbouring pixels are served from L1/L2.  Weights are stored
 // tap-major [kh*kw][C] so the per-tap weight vector is also one coalesced load.
-//   out = act( (sum_taps w*x + bias) * post_scale + post_shift )
+//   out = act( (sum_taps w*x + bias) * post_scale + post_shift ) * mul_in      (mul_in optional: the SGFN gate, dat_arch.py:123)
 #include "ff_common.h"
 
 struct DwParams {
-  const float* in; float* out; const float* w; const float* bias; const float* ps; const float* pt;
-  int ldi, ldo, B, H, W, C, Ho, Wo, KH, KW, sy, sx, py, px, act;
+  const float* in; float* out; const float* w; const float* bias; const float* ps; const float* pt; const float* mulin;
+  int ldm, ldi, ldo, B, H, W, C, Ho, Wo, KH, KW, sy, sx, py, px, act;
 };
 
 __global__ __launch_bounds__(256) void dwconv_vec4_kernel(DwParams p) {
@@ -41,7 +41,65 @@ __global__ __launch_bounds__(256) void dwconv_vec4_kernel(DwParams p) {
       if (p.ps) v = v * p.ps[c + e] + p.pt[c + e];
       r[e] = ff_act(v, p.act);
     }
+    if (p.mulin) r *= *reinterpret_cast<const f32x4*>(p.mulin + ((long long)(b * p.Ho + oy) * p.Wo + ox) * p.ldm + c);
     *reinterpret_cast<f32x4*>(p.out + ((long long)(b * p.Ho + oy) * p.Wo + ox) * p.ldo + c) = r;
+  }
+}
+
+// 3x3 / stride 1 / pad 1 specialisation (DAT's two depth-wise convs, dat_arch.py:109,403): a thread owns 4 channels of a
+// 4-row output strip, keeps the 9 tap weights in registers and slides a 3-column window down 6 input rows, so each
+// output costs 4.5 float4 loads instead of 9 and no per-tap weight loads or bounds branches.
+template <int ACT>
+__global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(DwParams p) {
+  const int c4n = p.C >> 2;
+  const int nstrip = (p.H + 3) >> 2;
+  const long long total = (long long)p.B * nstrip * p.W * c4n;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % c4n) * 4;
+    long long t = idx / c4n;
+    const int ox = (int)(t % p.W); t /= p.W;
+    const int y0 = (int)(t % nstrip) * 4;
+    const int b = (int)(t / nstrip);
+    f32x4 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f32x4*>(p.w + (long long)k * p.C + c);
+    f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : z4;
+    f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pt = z4;
+    if (p.ps) { ps = *reinterpret_cast<const f32x4*>(p.ps + c); pt = *reinterpret_cast<const f32x4*>(p.pt + c); }
+    f32x4 in[6][3];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int iy = y0 - 1 + r;
+      const bool oky = (unsigned)iy < (unsigned)p.H;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int ix = ox - 1 + k;
+        const bool ok = oky && (unsigned)ix < (unsigned)p.W;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p.in + (ok ? ((long long)(b * p.H + iy) * p.W + ix) * p.ldi + c : 0));
+        in[r][k] = ok ? u : z4;
+      }
+    }
+    f32x4 mul[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = p.mulin && y0 + r < p.H;
+      mul[r] = ok ? *reinterpret_cast<const f32x4*>(p.mulin + ((long long)(b * p.H + y0 + r) * p.W + ox) * p.ldm + c) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (y0 + r >= p.H) break;
+      f32x4 acc = z4;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc += in[r + ky][kx] * w[ky * 3 + kx];
+      acc = (acc + bias) * ps + pt;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = ff_act_c<ACT, false>(acc[e]) * mul[r][e];
+      *reinterpret_cast<f32x4*>(p.out + ((long long)(b * p.H + y0 + r) * p.W + ox) * p.ldo + c) = o;
+    }
   }
 }
 
@@ -65,22 +123,36 @@ __global__ __launch_bounds__(256) void dwconv_scalar_kernel(DwParams p) {
     }
     float v = acc + (p.bias ? p.bias[c] : 0.f);
     if (p.ps) v = v * p.ps[c] + p.pt[c];
-    p.out[((long long)(b * p.Ho + oy) * p.Wo + ox) * p.ldo + c] = ff_act(v, p.act);
+    float rr = ff_act(v, p.act);
+    if (p.mulin) rr *= p.mulin[((long long)(b * p.Ho + oy) * p.Wo + ox) * p.ldm + c];
+    p.out[((long long)(b * p.Ho + oy) * p.Wo + ox) * p.ldo + c] = rr;
   }
 }
 
 extern "C" int ff_dwconv2d(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int Ho, int Wo,
                            const float* w_tapmajor, const float* bias, int KH, int KW, int sy, int sx, int py, int px,
-                           const float* post_scale, const float* post_shift, int act, void* stream) {
+                           const float* post_scale, const float* post_shift, int act, const float* mul_in, int ldm, void* stream) {
   FF_CHECK_ARG(in && out && w_tapmajor, "ff_dwconv2d: null pointer");
   FF_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && ldi >= C && ldo >= C, "ff_dwconv2d: bad dims");
   FF_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "ff_dwconv2d: post scale/shift must come together");
   DwParams p;
-  p.in = in; p.out = out; p.w = w_tapmajor; p.bias = bias; p.ps = post_scale; p.pt = post_shift;
+  p.in = in; p.out = out; p.w = w_tapmajor; p.bias = bias; p.ps = post_scale; p.pt = post_shift; p.mulin = mul_in; p.ldm = ldm;
   p.ldi = ldi; p.ldo = ldo; p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo;
   p.KH = KH; p.KW = KW; p.sy = sy; p.sx = sx; p.py = py; p.px = px; p.act = act;
-  const bool v4 = (C % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)in & 15) == 0) &&
+  FF_CHECK_ARG(!mul_in || ldm >= C, "ff_dwconv2d: ldm too small");
+  const bool v4 = (C % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && (!mul_in || (ldm % 4 == 0 && ((uintptr_t)mul_in & 15) == 0)) && (((uintptr_t)in & 15) == 0) &&
                   (((uintptr_t)out & 15) == 0) && (((uintptr_t)w_tapmajor & 15) == 0);
+  if (v4 && KH == 3 && KW == 3 && sy == 1 && sx == 1 && py == 1 && px == 1 && Ho == H && Wo == W && out != in) {
+    const long long tot = (long long)B * ((H + 3) / 4) * W * (C / 4);
+    long long nbs = (tot + 255) / 256;
+    if (nbs > 256 * 32) nbs = 256 * 32;
+    auto go = [&](auto A) {
+      hipLaunchKernelGGL((dwconv3x3_strip_kernel<decltype(A)::value>), dim3((unsigned)nbs), dim3(256), 0, (hipStream_t)stream, p);
+    };
+    FF_DISPATCH_ACT(act, go);
+    FF_LAUNCH_CHECK("ff_dwconv2d");
+    return FF_OK;
+  }
   const long long total = (long long)B * Ho * Wo * (v4 ? C / 4 : C);
   long long nb = (total + 255) / 256;
   if (nb > 256 * 32) nb = 256 * 32;

@@ -53,22 +53,33 @@ __global__ __launch_bounds__(256) void dwconv3_gate_pool_kernel(const float* __r
   }
 }
 
+// sum of the per-workgroup partials: 16 channels x 16 partial-lanes per workgroup, 4 independent accumulators per thread
 __global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ part, int nch, int C, float invP, float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < C) {
     int i = r;
-    for (; i + 4 < nch; i += 8) { s0 += part[(long long)i * C + c]; s1 += part[(long long)(i + 4) * C + c]; }
-    for (; i < nch; i += 4) s0 += part[(long long)i * C + c];
+    for (; i + 48 < nch; i += 64) {
+      s0 += part[(long long)i * C + c];
+      s1 += part[(long long)(i + 16) * C + c];
+      s2 += part[(long long)(i + 32) * C + c];
+      s3 += part[(long long)(i + 48) * C + c];
+    }
+    for (; i < nch; i += 16) s0 += part[(long long)i * C + c];
   }
-  red[r][lane] = s0 + s1;
+  red[r][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (r == 0 && c < C) out[c] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * invP;
+  if (r == 0 && c < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][cl];
+    out[c] = s * invP;
+  }
 }
 
-extern "C" long long ff_dwconv3_gate_pool_workspace(int C) { return (long long)2048 * C; }
+extern "C" long long ff_dwconv3_gate_pool_workspace(int C) { return (long long)1024 * C; }
 
 extern "C" int ff_dwconv3_gate_pool(const float* in, int ldi, float* out, int ldo, int H, int W, int C, const float* w_tapmajor,
                                     const float* bias, float* pooled, float* work, long long work_floats, void* stream) {
@@ -78,12 +89,12 @@ extern "C" int ff_dwconv3_gate_pool(const float* in, int ldi, float* out, int ld
   const int cv = C / 4, ppb = 256 / cv;
   const long long P = (long long)H * W;
   long long nb = (P + ppb - 1) / ppb;
-  if (nb > 2048) nb = 2048;
+  if (nb > 1024) nb = 1024;      // 4 workgroups per CU: enough to stream at HBM rate, few enough partials to reduce
   FF_CHECK_ARG(work_floats >= nb * C, "ff_dwconv3_gate_pool: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(dwconv3_gate_pool_kernel, dim3((unsigned)nb), dim3(256), (size_t)ppb * cv * 16, st, in, ldi, out, ldo, H, W, C,
                      w_tapmajor, bias, work);
-  hipLaunchKernelGGL(pool_reduce_kernel, dim3((C + 63) / 64), dim3(256), 0, st, work, (int)nb, C, 1.0f / (float)P, pooled);
+  hipLaunchKernelGGL(pool_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, work, (int)nb, C, 1.0f / (float)P, pooled);
   FF_LAUNCH_CHECK("ff_dwconv3_gate_pool");
   return FF_OK;
 }

@@ -313,8 +313,7 @@ class DatHIP:
             y = ops.linear(ops.layernorm(x, *blk["n2"]), *blk["fc1"], act="gelu")
         c2 = y.shape[-1] // 2
         gte = ops.layernorm(y[..., c2:], *blk["sgn"])
-        gte = ops.dwconv2d(gte, *blk["sgc"])
-        z = ops.fma3(None, y[..., :c2], gte)
+        z = ops.dwconv2d(gte, *blk["sgc"], mul_in=y[..., :c2])                     # dw3x3(LN(x2)) * x1 in one pass
         return ops.linear(z, *blk["fc2"], res=x)
 
     def forward(self, lr: T, taps: Optional[dict] = None) -> T:

@@ -351,7 +351,8 @@ def vec_mlp(v: T, W1: T, b1: Optional[T], act1, W2: Optional[T] = None, b2: Opti
 
 
 def dwconv2d(x: T, w_tap: T, bias: Optional[T] = None, *, ksize=(3, 3), stride=(1, 1), pad=(1, 1),
-             post_scale: Optional[T] = None, post_shift: Optional[T] = None, act=None, out: Optional[T] = None) -> T:
+             post_scale: Optional[T] = None, post_shift: Optional[T] = None, act=None, out: Optional[T] = None,
+             mul_in: Optional[T] = None) -> T:
     xp, ldi, B, H, W, C = _nhwc(x, "dwconv2d.x")
     KH, KW = ksize
     if tuple(w_tap.shape) != (KH * KW, C) or not w_tap.is_contiguous():
@@ -361,8 +362,13 @@ def dwconv2d(x: T, w_tap: T, bias: Optional[T] = None, *, ksize=(3, 3), stride=(
     if out is None:
         out = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.float32)
     op, ldo, *_ = _nhwc(out, "dwconv2d.out")
+    mp, ldm = None, 0
+    if mul_in is not None:
+        mp, ldm, mb, mh, mw, mc = _nhwc(mul_in, "dwconv2d.mul_in")
+        if (mb, mh, mw, mc) != (B, Ho, Wo, C):
+            raise _lib.FFError("dwconv2d: mul_in shape mismatch")
     _lib.check(_L().ff_dwconv2d(xp, ldi, op, ldo, B, H, W, C, Ho, Wo, w_tap.data_ptr(), _ptr(bias), KH, KW, stride[0],
-                                stride[1], pad[0], pad[1], _ptr(post_scale), _ptr(post_shift), ACT[act], _stream()))
+                                stride[1], pad[0], pad[1], _ptr(post_scale), _ptr(post_shift), ACT[act], mp, ldm, _stream()))
     _note(2.0 * B * Ho * Wo * C * KH * KW, 4.0 * (B * H * W * C + B * Ho * Wo * C))
     return out
 

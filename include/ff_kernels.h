@@ -125,11 +125,11 @@ int ff_vec_mlp(const float* in, int B, int Cin, const float* W1, const float* b1
                const float* b2, int Cout, int act2, float post, float* out, void* stream);
 
 /* Depth-wise conv, NHWC, zero padding, weights tap-major [KH*KW][C]:
- *   out = act((sum w*x + bias) * post_scale + post_shift)
+ *   out = act((sum w*x + bias) * post_scale + post_shift) * mul_in[pixel][c]     (mul_in may be NULL)
  * dat_arch.py:109,403-407; nafnet_arch.py:78-81; large_kernel_attention.py:59-73; edge_enhancement.py:62. */
 int ff_dwconv2d(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int Ho, int Wo,
                 const float* w_tapmajor, const float* bias, int KH, int KW, int sy, int sx, int py, int px,
-                const float* post_scale, const float* post_shift, int act, void* stream);
+                const float* post_scale, const float* post_shift, int act, const float* mul_in, int ldm, void* stream);
 
 /* out = ka*a*ca[c]*pa[p] + kb*b*cb[c]*pb[p]   (b, ca, cb, pa, pb may be NULL; clamp01 clamps to [0,1]) */
 int ff_mix2(float* out, int ldo, const float* a, int lda, const float* b, int ldb, long long rows, int C, float ka,

@@ -314,6 +314,11 @@ def test_dwconv(dev, C, kh, kw, sy, sx):
     out = ops.dwconv2d(x.permute(0, 2, 3, 1).contiguous(), pack_dw(w), b, ksize=(kh, kw), stride=(sy, sx), pad=(kh // 2, kw // 2),
                        post_scale=ps, post_shift=pt, act="gelu")
     close(out.permute(0, 3, 1, 2), ref, 1e-5, "dwconv")
+    if (kh, kw) == (3, 3):                                  # fused SGFN gate product (dat_arch.py:123), strided mul_in slice
+        wide = rnd(1, 33, 29, 2 * C, dev=dev, seed=45)
+        out = ops.dwconv2d(x.permute(0, 2, 3, 1).contiguous(), pack_dw(w), b, mul_in=wide[..., :C])
+        ref = F.conv2d(x, w, b, padding=1, groups=C) * wide[..., :C].permute(0, 3, 1, 2)
+        close(out.permute(0, 3, 1, 2), ref, 1e-5, "dwconv*mul")
 
 
 def test_pointwise(dev):
