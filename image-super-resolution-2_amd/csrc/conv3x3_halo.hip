@@ -1,0 +1,265 @@
+// 3x3 / stride 1 / pad 1 convolution with the input tile resident in LDS ("halo" kernel), split-bf16 MFMA.
+//   hat_arch.py:121-130 (CAB conv 180->60->180), :768 (RHAG conv), :921-953 (conv_after_body / upsample trunk),
+//   dat_arch.py:396,772 (AIM / RG convs), nafnet_arch.py:187,193 (intro / ending), the 3x3 convs of the fusion stack.
+// The generic implicit GEMM (conv_gemm_bf16.hip) gathers, converts and stages every input element once PER FILTER TAP
+// (9x), which is what bounds it (~80 us for the 12.7 GFLOP CAB convs whose MFMA and HBM times are both ~15 us).
+// Here a workgroup owns a TH x 16 pixel tile: the (TH+2) x 18 halo tile of 64 input channels is loaded, split into
+// bf16 hi/lo and written to LDS ONCE, and the nine taps read it at shifted pixel rows -- the im2col is pure LDS
+// addressing.  Weights arrive pre-split and pre-tiled (prep.pack_conv3x3_halo) as one LDS image per (n-block,
+// 64-channel chunk, tap) and stream through a two-slot ring by LDS-DMA, overlapped with the 4 k-steps of the
+// previous tap.  Accumulators stay in registers over all chunks and taps (K = 9*Cin).
+//   LDS row (pixel or weight row) = [64 k hi | 64 k lo | 16 B pad] = 272 B = 68 dwords: conflict-free ds_read_b128.
+#include "ff_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct HaloParams {
+  const float* in; const unsigned char* w; const float* bias; const float* mul; const float* res; float* out;
+  int B, H, W, Cin, ldi, Cout, ldo, ldr, nchunk, tiles_x, tiles_y, nblk, act, shuffle;
+  float alpha;
+};
+
+#define HX_ROW 272
+#define HX_W 18
+
+template <int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
+  static_assert(WM * WN == 4, "four waves");
+  constexpr int TH = WM * MI * 2, NPX = (TH + 2) * HX_W, NPASS = (NPX + 15) / 16;
+  constexpr int BN = WN * NI * 32, TN = NI * 32;
+  constexpr int XBYTES = NPX * HX_ROW;
+  constexpr int WPIECES = (BN * HX_ROW + 1023) / 1024, WSLOT = WPIECES * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Xs = smem;
+  unsigned char* Ws = smem + XBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wr = wid / WN, wc = wid % WN;
+
+  const int ntile = p.tiles_x * p.tiles_y * p.B;
+  const int L = ff_xcd_remap(blockIdx.x, ntile * p.nblk);
+  const int nb = L % p.nblk;
+  int t = L / p.nblk;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int b = t / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const int n0 = nb * BN;
+
+  // ---- weight ring: tile index T = chunk*9 + tap, image [nblk][nchunk*9][WSLOT] --------------------------------
+  const unsigned char* wimg = p.w + (long long)nb * p.nchunk * 9 * WSLOT;
+  auto dma = [&](int T, int slot) {
+    const unsigned char* src = wimg + (long long)T * WSLOT + lane * 16;
+#pragma unroll
+    for (int i = 0; i < (WPIECES + 3) / 4; ++i) {
+      const int pc = wid + 4 * i;
+      if (pc < WPIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 1024),
+                                         (__attribute__((address_space(3))) void*)(Ws + slot * WSLOT + pc * 1024), 16, 0, 0);
+    }
+  };
+  const int ntiles = p.nchunk * 9;
+  dma(0, 0);
+
+  // ---- input halo staging: 16 lanes (float4 each) per pixel, 16 pixels per pass ---------------------------------
+  const int cq = (tid & 15) * 4, prow = tid >> 4;
+  int goff[NPASS];
+#pragma unroll
+  for (int j = 0; j < NPASS; ++j) {
+    const int hp = j * 16 + prow;
+    const int hy = hp / HX_W, hx = hp - hy * HX_W;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool ok = hp < NPX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    goff[j] = ok ? ((b * p.H + iy) * p.W + ix) * p.ldi + cq : -1;
+  }
+  f32x4 xr[NPASS];
+  auto load_x = [&](int chunk) {
+    const int c0 = chunk * 64;
+    const bool cok = c0 + cq < p.Cin;
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+      const bool ok = cok && goff[j] >= 0;
+      const f32x4 u = *reinterpret_cast<const f32x4*>(p.in + (ok ? goff[j] + c0 : 0));
+      xr[j] = ok ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_x = [&]() {
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+      const int hp = j * 16 + prow;
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float f = xr[j][e];
+        const __bf16 h = (__bf16)f;
+        hi[e] = h;
+        lo[e] = (__bf16)(f - (float)h);
+      }
+      if (hp < NPX) {
+        unsigned char* dst = Xs + hp * HX_ROW + (tid & 15) * 8;
+        *reinterpret_cast<bf16x4*>(dst) = hi;
+        *reinterpret_cast<bf16x4*>(dst + 128) = lo;
+      }
+    }
+  };
+  load_x(0);
+  store_x();
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane LDS byte offsets (tap (0,0)): pixel row of m-tile i, weight row of n-tile j
+  int aoff[MI], boff[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) aoff[i] = (((wr * MI + i) * 2 + (l31 >> 4)) * HX_W + (l31 & 15)) * HX_ROW + 16 * hh;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) boff[j] = (wc * TN + j * 32 + l31) * HX_ROW + 16 * hh;
+
+  int T = 0;
+  for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+    for (int tap = 0; tap < 9; ++tap, ++T) {
+      // own DMA pieces of tile T (and any prefetched input rows) have landed; the barrier then makes every wave's
+      // pieces and the staged input tile visible, and guarantees slot (T+1)&1 is no longer being read
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (T + 1 < ntiles) dma(T + 1, (T + 1) & 1);
+      if (tap == 7 && chunk + 1 < p.nchunk) load_x(chunk + 1);
+      const int dy = tap / 3, dx = tap - 3 * dy;
+      const unsigned char* xa = Xs + (dy * HX_W + dx) * HX_ROW;
+      const unsigned char* wb = Ws + (T & 1) * WSLOT;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          ah[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * s);
+          al[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * s + 128);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          bh[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s);
+          bl[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s + 128);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+    if (chunk + 1 < p.nchunk) {
+      __syncthreads();                 // every wave is done reading this chunk's input tile
+      store_x();                       // (made visible by the barrier at the top of the next tap)
+    }
+  }
+
+  // ---- epilogue: lane = output channel column, 16 pixels per m-tile ---------------------------------------------
+  auto epilogue = [&](auto ACTC) {
+    constexpr int ACT = decltype(ACTC)::value;
+    const bool has_res = p.res != nullptr;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wc * TN + j * 32 + l31;
+      if (n >= p.Cout) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+      const float mv = (p.mul ? p.mul[n] : 1.f) * p.alpha;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        long long oidx[16];
+        float rv[16];
+        bool okp[16];
+        const int ry0 = y0 + (wr * MI + i) * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int mrow = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const int oy = ry0 + (mrow >> 4), ox = x0 + (mrow & 15);
+          okp[r] = oy < p.H && ox < p.W;
+          if (p.shuffle == 2) {              // fused PixelShuffle(2): channel n = 4 co + 2 sy + sx -> pixel (2 oy + sy, 2 ox + sx)
+            const int co = n >> 2, sy = (n >> 1) & 1, sx = n & 1;
+            const long long pix = okp[r] ? ((long long)(b * 2 * p.H + 2 * oy + sy) * (2 * p.W) + 2 * ox + sx) : 0;
+            oidx[r] = pix * p.ldo + co;
+            rv[r] = has_res ? p.res[pix * p.ldr + co] : 0.f;
+          } else {
+            const long long pix = okp[r] ? ((long long)(b * p.H + oy) * p.W + ox) : 0;
+            oidx[r] = pix * p.ldo + n;
+            rv[r] = has_res ? p.res[pix * p.ldr + n] : 0.f;
+          }
+        }
+        if (ry0 + 1 < p.H && x0 + 15 < p.W) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p.out[oidx[r]] = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (okp[r]) p.out[oidx[r]] = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
+        }
+      }
+    }
+  };
+  FF_DISPATCH_ACT(p.act, epilogue)
+}
+
+template <int WM, int WN, int MI, int NI>
+static int launch_halo(HaloParams& p, hipStream_t st) {
+  constexpr int TH = WM * MI * 2, NPX = (TH + 2) * HX_W, BN = WN * NI * 32;
+  constexpr int WSLOT = ((BN * HX_ROW + 1023) / 1024) * 1024;
+  constexpr size_t lds = (size_t)NPX * HX_ROW + 2 * WSLOT;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  p.tiles_x = (p.W + 15) / 16;
+  p.tiles_y = (p.H + TH - 1) / TH;
+  p.nblk = (p.Cout + BN - 1) / BN;
+  const long long nblocks = (long long)p.tiles_x * p.tiles_y * p.B * p.nblk;
+  if (nblocks >= (1LL << 31)) { ff_set_error("ff_conv3x3_halo: grid too large"); return FF_ERR_ARG; }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, MI, NI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { ff_set_error("ff_conv3x3_halo: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return FF_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, MI, NI>), dim3((unsigned)nblocks), dim3(256), lds, st, p);
+  FF_LAUNCH_CHECK("ff_conv3x3_halo");
+  return FF_OK;
+}
+
+// bytes of the weight image prep.pack_conv3x3_halo must produce for (Cout, Cin, bn)
+extern "C" long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn) {
+  if (Cout <= 0 || Cin <= 0 || (bn != 32 && bn != 64 && bn != 128 && bn != 192)) return -1;
+  const long long slot = ((long long)bn * HX_ROW + 1023) / 1024 * 1024;
+  return (long long)((Cout + bn - 1) / bn) * ((Cin + 63) / 64) * 9 * slot;
+}
+
+extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const float* bias, const float* mul,
+                               const float* res, int ldr, float* out, int ldo, int B, int H, int W, int Cin, int Cout,
+                               int act, float alpha, int shuffle, void* stream) {
+  FF_CHECK_ARG(in && w_img && out, "ff_conv3x3_halo: null pointer");
+  FF_CHECK_ARG(shuffle == 0 || (shuffle == 2 && Cout % 4 == 0), "ff_conv3x3_halo: shuffle must be 0 or 2 (Cout %% 4 == 0)");
+  FF_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "ff_conv3x3_halo: bad dims");
+  FF_CHECK_ARG(Cin % 4 == 0 && ldi % 4 == 0 && ldi >= Cin && (((uintptr_t)in) & 15) == 0, "ff_conv3x3_halo: input rows must be 16-byte aligned, Cin %% 4 == 0");
+  FF_CHECK_ARG((((uintptr_t)w_img) & 15) == 0, "ff_conv3x3_halo: weight image must be 16-byte aligned");
+  FF_CHECK_ARG(ldo >= (shuffle ? Cout / 4 : Cout) && (!res || ldr >= (shuffle ? Cout / 4 : Cout)), "ff_conv3x3_halo: ldo / ldr too small");
+  FF_CHECK_ARG((long long)B * H * W * ldi < (1LL << 31), "ff_conv3x3_halo: input too large for 32-bit offsets");
+  FF_CHECK_ARG(in != out, "ff_conv3x3_halo: in-place convolution is not supported");
+  HaloParams p;
+  p.in = in; p.w = (const unsigned char*)w_img; p.bias = bias; p.mul = mul; p.res = res; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.ldi = ldi; p.Cout = Cout; p.ldo = ldo; p.ldr = ldr;
+  p.nchunk = (Cin + 63) / 64; p.act = act; p.alpha = alpha; p.shuffle = shuffle;
+  hipStream_t st = (hipStream_t)stream;
+  switch (bn) {
+    case 32: return launch_halo<4, 1, 2, 1>(p, st);    // 16x16 pixels x 32 channels
+    case 64: return launch_halo<4, 1, 2, 2>(p, st);    // 16x16 pixels x 64
+    case 128: return launch_halo<2, 2, 2, 2>(p, st);   //  8x16 pixels x 128
+    case 192: return launch_halo<2, 2, 2, 3>(p, st);   //  8x16 pixels x 192
+    default: ff_set_error("ff_conv3x3_halo: bn must be 32, 64, 128 or 192"); return FF_ERR_ARG;
+  }
+}

@@ -91,6 +91,14 @@ def gemm_mode() -> str:
     return _GEMM_MODE
 
 
+_HALO = _os.environ.get("FF_HALO", "1") != "0"     # LDS-resident 3x3 convolution (csrc/conv3x3_halo.hip); 0 = generic implicit GEMM
+
+
+def set_halo(on: bool) -> None:
+    global _HALO
+    _HALO = bool(on)
+
+
 def _split_weight(w: T, dynamic: bool, cin: int):
     """bf16 hi/lo planes [N][Kp] of a packed fp32 weight [N][taps*cin]; cached on the tensor object unless
     `dynamic`.  Per-tap padded (TAP) K layout when cin >= 32 and cin % 4 == 0, flat otherwise."""
@@ -182,6 +190,18 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
         _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, B, H, W, Cin, ldi, Ho, Wo, Cout, ldo, ldr,
                                   KH, KW, stride[0], stride[1], pad[0], pad[1], ACT[act], float(alpha), shuffle, tile_hint,
                                   _stream()))
+    elif (_HALO and _GEMM_MODE == "bf16x3" and (KH, KW) == (3, 3) and tuple(stride) == (1, 1) and tuple(pad) == (1, 1)
+          and not dynamic_w and Cin >= 32 and Cin % 4 == 0 and ldi % 4 == 0 and xp % 16 == 0
+          and (Cout <= 64 or Cin >= 128)        # measured (profiles/r01_conv3x3_halo_vs_igemm.txt): wins there, ties / loses for 64 -> 180..256
+          and H * W >= 1024 and xp != op and B * H * W * ldi < 2 ** 31):
+        img = getattr(w, "_ff_halo", None)
+        if img is None:
+            from . import prep as _prep
+            bn = _prep.halo_bn(Cout)
+            img = (_prep.pack_conv3x3_halo(w, Cin, bn), bn)
+            w._ff_halo = img
+        _lib.check(_L().ff_conv3x3_halo(xp, ldi, img[0].data_ptr(), img[1], _ptr(bias), _ptr(mul), rp, ldr, op, ldo, B, H, W,
+                                        Cin, Cout, ACT[act], float(alpha), shuffle, _stream()))
     else:
         aligned = (ldi % 4 == 0) and (xp % 16 == 0)
         hi, lo, Kp, Cp, _ = _split_weight(w, dynamic_w, Cin if aligned else 0)

@@ -65,6 +65,32 @@ def pack_token_mlp(w1: T, b1: T, w2: T, b2: T) -> dict:
     return dict(ht=ht, K=K, N=N, w=tiles, b1=b1p.contiguous(), b2=b2.contiguous())
 
 
+def halo_bn(cout: int) -> int:
+    """Output channels per workgroup of ff_conv3x3_halo: least padding, ties to the wider tile."""
+    if cout <= 32:
+        return 32
+    return min((192, 128, 64), key=lambda bn: (-(-cout // bn) * bn, -bn))
+
+
+def pack_conv3x3_halo(wp: T, cin: int, bn: int) -> T:
+    """Weight image of ff_conv3x3_halo from a packed 3x3 weight [Cout, 9*cin] (tap-major, pack_conv):
+    bf16 [nblk][nchunk][9][bn rows x (64 hi | 64 lo | 8 pad)] with every (nblk, chunk, tap) record padded to 1 KiB."""
+    cout = wp.shape[0]
+    assert wp.shape[1] == 9 * cin
+    nblk, nchunk = -(-cout // bn), -(-cin // 64)
+    w = torch.zeros(nblk * bn, 9, nchunk * 64, device=wp.device)
+    w[:cout, :, :cin] = wp.reshape(cout, 9, cin)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    rows = torch.zeros(nblk, nchunk, 9, bn, 136, device=wp.device, dtype=torch.bfloat16)
+    rows[..., :64] = hi.reshape(nblk, bn, 9, nchunk, 64).permute(0, 3, 2, 1, 4)
+    rows[..., 64:128] = lo.reshape(nblk, bn, 9, nchunk, 64).permute(0, 3, 2, 1, 4)
+    slot = (bn * 272 + 1023) // 1024 * 1024
+    img = torch.zeros(nblk * nchunk * 9, slot // 2, device=wp.device, dtype=torch.bfloat16)
+    img[:, :bn * 136] = rows.reshape(nblk * nchunk * 9, bn * 136)
+    return img.contiguous()
+
+
 def pack_token_linear(w: T, b: Optional[T]) -> dict:
     """Weights of ff_token_linear: [N, K<=192] -> bf16 [NT][2][32][kpad] hi/lo tiles (kpad = 64/128/192), bias padded."""
     N, K = w.shape

@@ -84,6 +84,19 @@ int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long long M, int 
                  const float* gamma, const float* beta, float eps, const void* w_tiles, const float* b1_padded,
                  const float* b2, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution with the input tile resident in LDS (csrc/conv3x3_halo.hip), bf16x3 MFMA:
+ *   out = act(conv3x3(in) + bias) * mul[co] * alpha + res        (shuffle = 2: PixelShuffle(2) fused into the store)
+ * Same arithmetic as ff_conv2d_bf16s(nterms = 3) but the (TH+2) x 18 pixel halo tile is split to bf16 hi/lo and staged
+ * once per 64-channel chunk instead of once per filter tap.  Replaces nn.Conv2d(k=3, s=1, p=1) of hat_arch.py:121-130
+ * (CAB), :768, :921-953; dat_arch.py:396,772; nafnet_arch.py:187,193 and the fusion stack's 3x3 convolutions.
+ * bn in {32, 64, 128, 192} = output channels per workgroup.  w_img: prep.pack_conv3x3_halo image
+ * [ceil(Cout/bn)][ceil(Cin/64)][9 taps][bn rows x (64 hi | 64 lo | 8 pad) bf16, padded to 1 KiB], of
+ * ff_conv3x3_halo_weight_bytes(Cout, Cin, bn) bytes (-1: bad arguments).  Needs Cin % 4 == 0, 16-byte aligned rows. */
+long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn);
+int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const float* bias, const float* mul,
+                    const float* res, int ldr, float* out, int ldo, int B, int H, int W, int Cin, int Cout,
+                    int act, float alpha, int shuffle, void* stream);
+
 /* Token-stationary linear layer for K <= 192 (csrc/token_linear.hip), bf16x3 MFMA:
  *   out = res + res2*res2_scale[n] + act( LayerNorm?(x) . W^T + bias )        (gamma == NULL: no LayerNorm)
  * x is read once and kept in registers, W streams through LDS by DMA.  Replaces nn.LayerNorm + nn.Linear (+GELU,

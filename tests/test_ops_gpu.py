@@ -86,11 +86,49 @@ def test_conv2d_epilogue_residual_mul_alpha_and_slices(dev, gemm_mode):
     assert obuf[..., :16].abs().max() == 0 and obuf[..., 80:].abs().max() == 0
 
 
-def test_conv2d_pixel_shuffle(dev, gemm_mode):
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act", [
+    (1, 48, 48, 180, 60, "gelu"),      # CAB conv1: 3 channel chunks, bn 64 (16x16-pixel tiles)
+    (2, 37, 45, 128, 180, None),       # ragged tiles, batch 2, bn 192 (8x16 tiles)
+    (1, 40, 33, 180, 180, "lrelu"),    # RHAG conv
+    (1, 64, 64, 64, 3, "sigmoid"),     # bn 32
+    (1, 35, 64, 128, 128, None),       # bn 128
+    (1, 32, 32, 128, 256, "relu"),     # two 128-wide n-blocks
+    (1, 32, 40, 36, 40, None),         # Cin < 64 (zero-padded chunk), ragged n-block
+    (1, 32, 40, 132, 200, None),       # ragged last chunk, two ragged n-blocks
+])
+def test_conv3x3_halo_matches_torch(dev, B, H, W, Cin, Cout, act):
+    """LDS-resident 3x3 kernel (bf16x3 only) against PyTorch fp32, with residual / per-channel scale / strided views."""
     from isr2_amd import ops
     from isr2_amd.prep import pack_conv
-    x = rnd(1, 64, 12, 14, dev=dev, seed=9)
-    w = rnd(256, 64, 3, 3, dev=dev, seed=10, scale=0.05)
+    prev = ops.gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        wide = rnd(B, H, W, Cin + 8, dev=dev, seed=60)
+        x = wide[..., 4:4 + Cin]
+        w = rnd(Cout, Cin, 3, 3, dev=dev, seed=61, scale=1.0 / math.sqrt(9 * Cin))
+        b = rnd(Cout, dev=dev, seed=62, scale=0.1)
+        mul = rnd(Cout, dev=dev, seed=63)
+        res = rnd(B, H, W, Cout, dev=dev, seed=64)
+        wp = pack_conv(w)
+        out = ops.conv2d(x, wp, b, ksize=(3, 3), pad=(1, 1), act=act, res=res, mul=mul, alpha=0.7)
+        assert getattr(wp, "_ff_halo", None) is not None, "halo kernel was not selected"
+        f = {"gelu": F.gelu, "relu": F.relu, "sigmoid": torch.sigmoid, "lrelu": lambda t: F.leaky_relu(t, 0.01), None: lambda t: t}[act]
+        ref = res + 0.7 * mul * f(F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)).permute(0, 2, 3, 1)
+        close(out, ref, GEMM_TOL["bf16x3"], "conv3x3 halo")
+        ops.set_halo(False)
+        out2 = ops.conv2d(x, pack_conv(w), b, ksize=(3, 3), pad=(1, 1), act=act, res=res, mul=mul, alpha=0.7)
+        close(out, out2, GEMM_TOL["bf16x3"], "halo vs implicit GEMM")
+    finally:
+        ops.set_halo(True)
+        ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("hw,cin", [((12, 14), 64), ((36, 40), 128)])   # implicit GEMM; LDS-resident 3x3 kernel (bf16x3)
+def test_conv2d_pixel_shuffle(dev, gemm_mode, hw, cin):
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_conv
+    x = rnd(1, cin, hw[0], hw[1], dev=dev, seed=9)
+    w = rnd(256, cin, 3, 3, dev=dev, seed=10, scale=0.05)
     b = rnd(256, dev=dev, seed=11, scale=0.1)
     ref = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2)
     out = ops.conv2d(x.permute(0, 2, 3, 1).contiguous(), pack_conv(w), b, ksize=(3, 3), pad=(1, 1), shuffle=2)

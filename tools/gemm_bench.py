@@ -14,6 +14,8 @@ SHAPES = [  # name, B,H,W,Cin,Cout,k
     ("naf c1 128->256 @512", 1, 512, 512, 128, 256, 1), ("naf c1 256->512 @256", 1, 256, 256, 256, 512, 1),
     ("naf c1 512->1024 @128", 1, 128, 128, 512, 1024, 1), ("naf c1 1024->2048 @64", 1, 64, 64, 1024, 2048, 1),
     ("naf c3 1024->1024 @64", 1, 64, 64, 1024, 1024, 1), ("refine 3x3 64->64 @1024", 1, 1024, 1024, 64, 64, 3),
+    ("dat 3x3 180->180 b", 1, 256, 256, 180, 180, 3), ("last 3x3 64->3 @1024", 1, 1024, 1024, 64, 3, 3),
+    ("naf 3x3 64->64 @512", 1, 512, 512, 64, 64, 3), ("edge 3x3 64->32 @1024", 1, 1024, 1024, 64, 32, 3),
     ("hier 3x3 73->64 @1024", 1, 1024, 1024, 73, 64, 3), ("up 3x3 64->256 @256", 1, 256, 256, 64, 256, 3),
     ("up 3x3 64->256 @512", 1, 512, 512, 64, 256, 3), ("conv 3->64 @1024", 1, 1024, 1024, 3, 64, 3),
 ]
@@ -23,6 +25,8 @@ def main():
     if args and args[0] in ops.GEMM_MODES:
         ops.set_gemm_mode(args.pop(0))
     print("mode", ops.gemm_mode())
+    if args and args[0] == "nohalo":
+        args.pop(0); ops.set_halo(False)
     hints = [int(a) for a in args] or [0]
     dev = torch.device("cuda:0")
     for name, B, H, W, Ci, Co, k in SHAPES:
