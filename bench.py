@@ -10,8 +10,10 @@ eager Python launch loop is captured once), inputs are resident in HBM before th
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how roofline / cpu_baseline are defined.
 """
 import argparse
+import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -196,8 +198,13 @@ def main():
         _, t_fus = _timed(lambda: model.fusion.forward(lr, {"hat": hat_o, "dat": dat_o, "nafnet": naf_o}))
         stages = {"hat_ms": round(t_hat, 2), "dat_ms": round(t_dat, 2), "nafnet_ms": round(t_naf, 2), "fusion_ms": round(t_fus, 2),
                   "note": "eager launches (includes Python launch gaps the graph replay does not have)"}
-        with ops.profile() as prof:
-            model(lr)
+        ms_flag = model.multi_stream
+        model.multi_stream = False                      # per-kernel durations in isolation: no other stream sharing the CUs
+        try:
+            with ops.profile() as prof:
+                model(lr)
+        finally:
+            model.multi_stream = ms_flag
         agg = {}
         for name, ms, fl, by in prof.records():
             a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
@@ -207,18 +214,38 @@ def main():
         achieved = fl_l / (ms_l * 1e-3) / 1e12 if ms_l > 0 else 0.0
         mode = ops.gemm_mode()
         peak = PEAK_TF[mode]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_v2.json")
-        if os.path.exists(tpath):                       # PMC counters come from a separate rocprofv3 pass (profiles/)
-            traffic = json.load(open(tpath))["conv_igemm_all_variants"]["hbm_MB_per_launch"] * 1e6
-        roof = {"bound": "mfma", "kernel": "conv_igemm_bf16_kernel / conv_igemm_kernel (ff_conv2d: every Linear / Conv2d of the path)",
+        traffic, tnote = None, "no PMC profile committed"
+        def _ver(f):
+            m = re.search(r"_v(\d+)\.json$", f)
+            return int(m.group(1)) if m else -1
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_v*.json")), key=lambda f: (os.path.basename(f)[:3], _ver(f)))
+        tdoc = None
+        if tfiles:                                      # PMC counters come from separate rocprofv3 passes (tools/pmc_traffic.py)
+            tdoc = json.load(open(tfiles[-1]))
+            traffic = tdoc["conv_igemm_all_variants"]["hbm_MB_per_launch"] * 1e6
+            tnote = "HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/" + os.path.basename(tfiles[-1])
+        roof = {"bound": "mfma", "kernel": "ff_conv2d*: conv_igemm_bf16_kernel (all tile variants) + conv3x3_halo_kernel (f32 mode: conv_igemm_kernel) -- every Conv2d and every Linear with K > 192",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": traffic, "traffic_note": "HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r01_pmc_hbm_traffic_v2.json",
+                "traffic": traffic, "traffic_note": tnote,
                 "algorithmic_bytes_per_launch": 1e6 * (mf[0][3] + mf[1][3]) / max(n_l, 1) / 1e6,
                 "mfma_flops_per_algorithmic_flop": MFMA_PER_ALGO_FLOP[mode], "executed_mfma_frac": achieved * MFMA_PER_ALGO_FLOP[mode] / peak,
                 "launches_per_tile": n_l, "avg_launch_us": 1e3 * ms_l / max(n_l, 1),
                 "algorithmic_gflop_per_launch": fl_l / max(n_l, 1) / 1e9,
                 "share_of_tile_time": ms_l / max(sum(a[1] for a in agg.values()), 1e-9)}
+        # the two other large kernel families, against the roofline that bounds each (same HIP-event accounting)
+        def _fam(name, bound, peak_v, unit, key):
+            a = agg.get(name)
+            if not a or a[1] <= 0:
+                return None
+            ach = (a[3] / (a[1] * 1e-3) / 1e9) if bound == "hbm" else (a[2] / (a[1] * 1e-3) / 1e12)
+            tr = tdoc[key]["hbm_MB_per_launch"] * 1e6 if tdoc and key in tdoc else None
+            return {"kernel": name, "bound": bound, "achieved": ach, "peak": peak_v, "unit": unit, "frac": ach / peak_v,
+                    "traffic": tr, "launches_per_tile": a[0], "avg_launch_us": 1e3 * a[1] / a[0],
+                    "algorithmic_bytes_per_launch": a[3] / a[0], "algorithmic_gflop_per_launch": a[2] / a[0] / 1e9}
+        roof["other_kernels"] = [r for r in (
+            _fam("token_linear", "hbm", 8000.0, "GB/s", "token_linear_all_variants"),
+            _fam("window_attn", "mfma", peak, "TFLOP/s", "window_attn_all_variants"),
+            _fam("token_mlp", "mfma", peak, "TFLOP/s", "token_mlp")) if r]
         breakdown = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / max(v[1], 1e-9) / 1e9, 2),
                          "gbps": round(v[3] / max(v[1], 1e-9) / 1e6, 1)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
 

@@ -99,6 +99,9 @@ def set_halo(on: bool) -> None:
     _HALO = bool(on)
 
 
+_PAD_PITCH = _os.environ.get("FF_PAD_PITCH", "1") != "0"
+
+
 def _split_weight(w: T, dynamic: bool, cin: int):
     """bf16 hi/lo planes [N][Kp] of a packed fp32 weight [N][taps*cin]; cached on the tensor object unless
     `dynamic`.  Per-tap padded (TAP) K layout when cin >= 32 and cin % 4 == 0, flat otherwise."""
@@ -289,7 +292,10 @@ def token_linear(x: T, pk: dict, *, gamma: Optional[T] = None, beta: Optional[T]
     if K != pk["K"]:
         raise _lib.FFError("token_linear: K mismatch")
     N = pk["N"]
-    out = torch.empty(tuple(x.shape[:-1]) + (N,), device=x.device, dtype=torch.float32)
+    # wide outputs (qkv, fc1) get a row pitch that is a multiple of 32 floats: every 32-column store segment of the kernel
+    # is then one whole 128-byte line (no partial-line writes); consumers take the pitch as their ld argument
+    ldo = (N + 31) // 32 * 32 if (_PAD_PITCH and N > 192) else N
+    out = torch.empty(tuple(x.shape[:-1]) + (ldo,), device=x.device, dtype=torch.float32)[..., :N]
     rp, ldr, r2p, ldr2 = None, 0, None, 0
     if res is not None:
         rp, ldr, rr, rc = rows_view(res, "token_linear.res")
@@ -299,7 +305,7 @@ def token_linear(x: T, pk: dict, *, gamma: Optional[T] = None, beta: Optional[T]
         r2p, ldr2, rr, rc = rows_view(res2, "token_linear.res2")
         if rr != rows or rc != N or res2_scale is None or res2_scale.numel() != N:
             raise _lib.FFError("token_linear: res2 shape mismatch")
-    _lib.check(_L().ff_token_linear(xp, ldx, out.data_ptr(), N, rows, K, pk["kpad"], N, pk["nt"], _ptr(gamma), _ptr(beta), float(eps),
+    _lib.check(_L().ff_token_linear(xp, ldx, out.data_ptr(), ldo, rows, K, pk["kpad"], N, pk["nt"], _ptr(gamma), _ptr(beta), float(eps),
                                     pk["w"].data_ptr(), _ptr(pk["b"]), ACT[act], rp, ldr, r2p, ldr2, _ptr(res2_scale), _stream()))
     _note(2.0 * rows * N * K, 4.0 * (rows * K + rows * N * (1 + (res is not None) + (res2 is not None))))
     return out

@@ -1,0 +1,61 @@
+"""Builds profiles/*_pmc_hbm_traffic_*.json from two rocprofv3 counter passes (profiling aid, not part of the product).
+
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_f --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_w --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline
+  python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r01_pmc_hbm_traffic_v10.json
+
+Counter unit = KiB.  HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half of a wide coalesced read
+stream (MI355X_MICROARCH.md, HBM / rocprofv3 section); WRITE_SIZE is exact.  The two counters are collected in separate passes."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0][:140]
+        a = agg[name]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    fdir, wdir, out = sys.argv[1:4]
+    fe, wr = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fe) | set(wr)):
+        cf, vf = fe.get(k, [0, 0.0])
+        cw, vw = wr.get(k, [0, 0.0])
+        calls = max(cf, cw)
+        if calls == 0:
+            continue
+        fk, wk = vf / max(cf, 1), vw / max(cw, 1)
+        kernels[k] = {"calls": calls, "fetch_KiB_per_call_raw": fk, "write_KiB_per_call": wk,
+                      "hbm_MB_per_call_corrected": (2 * fk + wk) * 1024 / 1e6}
+
+    def family(pred):
+        sel = [v for k, v in kernels.items() if pred(k)]
+        calls = sum(v["calls"] for v in sel)
+        mb = sum(v["calls"] * v["hbm_MB_per_call_corrected"] for v in sel)
+        return {"launches": calls, "hbm_MB_per_launch": mb / max(calls, 1), "hbm_MB_total": mb}
+
+    doc = {"note": __doc__.split("\n\n")[-1].replace("\n", " "), "kernels": kernels,
+           "conv_igemm_all_variants": family(lambda k: "conv_igemm" in k or "conv3x3_halo" in k),
+           "token_linear_all_variants": family(lambda k: "token_linear" in k),
+           "window_attn_all_variants": family(lambda k: "window_attn" in k),
+           "token_mlp": family(lambda k: "token_mlp" in k),
+           "whole_forward": family(lambda k: True)}
+    json.dump(doc, open(out, "w"), indent=1)
+    for k in ("conv_igemm_all_variants", "token_linear_all_variants", "window_attn_all_variants", "token_mlp", "whole_forward"):
+        print(k, doc[k])
+
+
+if __name__ == "__main__":
+    main()
