@@ -1,0 +1,144 @@
+"""Drop-in boundary on the GPU: the plugin function the harness calls (reference test.py:50 -> io.py:188 main), its
+tiled fallback (io.py:82-121, 222-228) and size-independent properties of the path at the bench size (256x256 tile,
+BASELINE configs[1]) that no CPU oracle run can cover in seconds."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def hip_model(dev, synth_sd):
+    from isr2_amd import ops
+    from isr2_amd.model import FreqFusionHIP
+    ops.set_gemm_mode("bf16x3")
+    return FreqFusionHIP(synth_sd, dev)
+
+
+def test_plugin_main_writes_reference_png(tmp_path, dev, monkeypatch):
+    """BASELINE config 1 through the plugin: PNG in -> PNG out, same basenames, sorted case-insensitive glob, bytes within
+    1 LSB of what the reference's own plugin wrote for the same input and weights (tests/golden/c48_u8.npz)."""
+    import models.team29_FreqFusion.io as plug
+    g = np.load(os.path.join(HERE, "golden", "c48_u8.npz"))
+    lr_u8 = (g["lr"][0].transpose(1, 2, 0) * 255.0).round().astype(np.uint8)
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    Image.fromarray(lr_u8).save(src / "a_case.png")
+    Image.fromarray(lr_u8[:32, :40]).save(src / "B_small.PNG")               # upper-case extension, non-square
+    Image.fromarray(lr_u8).save(src / "ignored.jpg")                         # jpgs are only used when there is no png
+    monkeypatch.setenv("FREQFUSION_PRETRAINED", str(tmp_path / "no_such_dir"))  # -> seeded synthetic weights (1234)
+    plug.main(model_dir=str(tmp_path / "missing_fusion.pth"), input_path=str(src), output_path=str(dst), device=dev)
+    assert sorted(os.listdir(dst)) == ["B_small.PNG", "a_case.png"]
+    out = np.array(Image.open(dst / "a_case.png").convert("RGB"))
+    assert out.shape == (192, 192, 3)
+    diff = np.abs(out.astype(np.int16) - g["png_u8"].astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
+    assert np.array(Image.open(dst / "B_small.PNG")).shape == (128, 160, 3)
+
+
+def test_plugin_main_empty_directory(tmp_path, dev, monkeypatch):
+    import models.team29_FreqFusion.io as plug
+    monkeypatch.setenv("FREQFUSION_PRETRAINED", str(tmp_path / "no_such_dir"))
+    (tmp_path / "in").mkdir()
+    plug.main(model_dir="nope.pth", input_path=str(tmp_path / "in"), output_path=str(tmp_path / "out"), device=dev)
+    assert os.listdir(tmp_path / "out") == []
+
+
+def test_tiled_forward_matches_reference_golden(dev):
+    """ff_tile_accum / ff_tile_normalize blending against the output of the reference's own _tiled_forward
+    (tests/golden/tiled_37x53.npz, generated with the stand-in model below)."""
+    import models.team29_FreqFusion.io as plug
+    g = np.load(os.path.join(HERE, "golden", "tiled_37x53.npz"))
+
+    def standin(t):                      # the stand-in of tests/golden/make_golden.py (test-side helper, not product code)
+        up = torch.nn.functional.interpolate(t, scale_factor=4, mode="bilinear", align_corners=False)
+        return up * 0.9 + 0.05 * t.mean()
+
+    out = plug._tiled_forward(standin, torch.from_numpy(g["lr"]).to(dev), tile_size=16, overlap=4, scale=4, device=dev)
+    assert (out.cpu() - torch.from_numpy(g["out"])).abs().max().item() < 2e-6
+
+
+def test_oom_falls_back_to_overlap_tiles(tmp_path, dev, hip_model, monkeypatch):
+    """reference io.py:222-228: an 'out of memory' RuntimeError on the whole image switches to 128/32 tiles."""
+    import models.team29_FreqFusion.io as plug
+    from oracle import freqfusion_oracle as O
+    rng = np.random.default_rng(5)
+    img = (rng.random((140, 150, 3)) * 255).astype(np.uint8)
+    (tmp_path / "in").mkdir()
+    Image.fromarray(img).save(tmp_path / "in" / "big.png")
+    calls = []
+
+    class Flaky:
+        def __call__(self, x):
+            calls.append(tuple(x.shape[-2:]))
+            if x.shape[-1] > 128 or x.shape[-2] > 128:
+                raise RuntimeError("HIP out of memory. Tried to allocate 1.00 GiB")
+            return hip_model(x)
+
+    monkeypatch.setattr(plug, "_build_and_load", lambda model_dir, device: Flaky())
+    plug.main(model_dir="x.pth", input_path=str(tmp_path / "in"), output_path=str(tmp_path / "out"), device=dev)
+    assert calls[0] == (140, 150) and all(c == (128, 128) for c in calls[1:]) and len(calls) == 1 + 4
+    got = np.array(Image.open(tmp_path / "out" / "big.png").convert("RGB")).astype(np.int16)
+    lr = torch.from_numpy(img.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+    ref = O.tiled_forward(lambda t: hip_model(t.to(dev)).cpu(), lr, tile=128, overlap=32, scale=4)   # oracle blending, same tiles
+    ref_u8 = (ref.squeeze(0).clamp(0, 1).permute(1, 2, 0).numpy() * 255.0).round().astype(np.int16)
+    d = np.abs(got - ref_u8)
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+def test_full_size_tile_properties(dev, hip_model, synth_sd):
+    """256x256 -> 1024x1024 (the bench workload).  The CPU oracle needs minutes here, so the checks are properties:
+    finite and in range, bit-exact run to run, bit-exact between the three-stream and the one-stream schedule, bit-exact
+    between HIP-graph replay and eager launches, and >= 100 dB between the split-bf16 and the exact-fp32 contraction."""
+    from isr2_amd import ops
+    from isr2_amd.model import FreqFusionHIP
+    from oracle import freqfusion_oracle as O
+    rng = np.random.default_rng(2)
+    f = np.fft.fftfreq(256)
+    amp = 1.0 / np.maximum(np.hypot(*np.meshgrid(f, f, indexing="ij")), 1.0 / 256)
+    noise = np.fft.ifft2(np.fft.fft2(rng.standard_normal((3, 256, 256))) * amp).real
+    noise = (noise - noise.min()) / (noise.max() - noise.min())
+    lr = torch.from_numpy(noise.astype(np.float32)).unsqueeze(0).to(dev)
+
+    a = hip_model(lr).clone()
+    assert tuple(a.shape) == (1, 3, 1024, 1024) and torch.isfinite(a).all()
+    assert a.min().item() >= -0.5 and a.max().item() <= 1.5
+    b = hip_model(lr).clone()
+    assert torch.equal(a, b), "not deterministic"
+    flag = hip_model.multi_stream
+    try:
+        hip_model.multi_stream = not flag
+        c = hip_model(lr).clone()
+    finally:
+        hip_model.multi_stream = flag
+    assert torch.equal(a, c), "stream schedule changes the result"
+
+    static = lr.clone()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gout = hip_model(static)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a, gout), "graph replay differs from eager"
+
+    ops.set_gemm_mode("f32")
+    try:
+        exact = FreqFusionHIP(synth_sd, dev)(lr)
+    finally:
+        ops.set_gemm_mode("bf16x3")
+    psnr = O.psnr(a.cpu(), exact.cpu())
+    print("256x256: PSNR(bf16x3, f32) =", psnr)
+    assert psnr >= 100.0
