@@ -108,12 +108,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    dev = torch.device(f"cuda:{local_rank}")
+    # one rank per GPU.  (Rehearsal on a box with fewer GPUs than ranks: FF_DIST_BACKEND=gloo lets several ranks share a
+    # card -- RCCL refuses that -- so the whole N>1 code path can be exercised on one MI355X; never used for a result.)
+    backend = os.environ.get("FF_DIST_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPUs visible (one rank per GPU over RCCL)")
+    dev = torch.device(f"cuda:{local_rank % ndev}")
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from isr2_amd import ops
     from isr2_amd.model import FreqFusionHIP
@@ -259,7 +268,7 @@ def main():
                                    f"{tile}x{tile} LR tile -> {4 * tile}x{4 * tile} per step per GPU (BASELINE configs[1]); "
                                    "seeded synthetic weights (172.3 M params), 1/f-noise tiles",
                        "tile": tile, "tiles_per_step_per_gpu": 1,
-                       "parallelism": f"tile-sharded x{world}, weights RCCL-broadcast once ({bcast_s * 1e3:.1f} ms), no per-tile collectives",
+                       "parallelism": f"tile-sharded x{world}, weights {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'}-broadcast once ({bcast_s * 1e3:.1f} ms), no per-tile collectives",
                        "launch": "hipGraph replay" if graph is not None else "eager"},
             "path_tflops": world * args.steps * flop_per_tile / elapsed / 1e12,
             "roofline": roof, "stage_ms_per_tile": stages, "kernel_breakdown_ms_per_tile": breakdown,

@@ -28,28 +28,39 @@ def shard_list(items: Sequence, rank: int, world: int) -> List:
     return list(items[b:e])
 
 
+ALIGN = 64          # floats: every tensor starts on a 256-byte boundary of the flat buffer (kernels need 16-byte aligned rows)
+
+
+def _numel(shape) -> int:
+    return int(np.prod(shape)) if len(shape) else 1
+
+
+def _offsets(spec):
+    offs, off = [], 0
+    for _, s, _ in spec:
+        offs.append(off)
+        off += (_numel(s) + ALIGN - 1) // ALIGN * ALIGN
+    return offs, off
+
+
 def flat_size(spec) -> int:
-    return sum(int(np.prod(s)) if len(s) else 1 for _, s, _ in spec)
+    """Floats in the broadcast buffer (each tensor padded to a multiple of ALIGN)."""
+    return _offsets(spec)[1]
 
 
 def broadcast_state_dict(sd_on_src, spec, rank: int, world: int, device, src: int = 0) -> "OrderedDict[str, T]":
     """Every rank returns the state dict of `spec` (name, shape, kind) holding rank `src`'s values.
-    ONE flat fp32 broadcast (690 MB for the full model): per-tensor collectives would be latency bound."""
+    ONE flat fp32 broadcast (690 MB for the full model): per-tensor collectives would be latency bound.
+    The returned tensors are views into the flat buffer, each 256-byte aligned."""
     import torch.distributed as dist
-    total = flat_size(spec)
-    flat = torch.empty(total, device=device, dtype=torch.float32)
+    offs, total = _offsets(spec)
+    flat = torch.zeros(total, device=device, dtype=torch.float32)
     if rank == src:
-        off = 0
-        for n, s, _ in spec:
-            k = int(np.prod(s)) if len(s) else 1
-            flat[off:off + k].copy_(sd_on_src[n].reshape(-1).to(device, torch.float32))
-            off += k
+        for (n, s, _), off in zip(spec, offs):
+            flat[off:off + _numel(s)].copy_(sd_on_src[n].reshape(-1).to(device, torch.float32))
     if world > 1:
         dist.broadcast(flat, src=src)
     out: "OrderedDict[str, T]" = OrderedDict()
-    off = 0
-    for n, s, _ in spec:
-        k = int(np.prod(s)) if len(s) else 1
-        out[n] = flat[off:off + k].reshape(tuple(s))
-        off += k
+    for (n, s, _), off in zip(spec, offs):
+        out[n] = flat[off:off + _numel(s)].reshape(tuple(s))
     return out

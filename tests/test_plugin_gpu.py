@@ -142,3 +142,15 @@ def test_full_size_tile_properties(dev, hip_model, synth_sd):
     psnr = O.psnr(a.cpu(), exact.cpu())
     print("256x256: PSNR(bf16x3, f32) =", psnr)
     assert psnr >= 100.0
+
+
+def test_model_from_broadcast_state_dict(dev, hip_model, synth_sd):
+    """The N>1 ranks of bench.py build the model from the flat device buffer the RCCL broadcast filled
+    (parallel.broadcast_state_dict): same output, bit for bit, as the model built from the host state dict."""
+    from isr2_amd.model import FreqFusionHIP
+    from isr2_amd.parallel import broadcast_state_dict
+    from isr2_amd.weights import param_spec
+    sd_dev = broadcast_state_dict(synth_sd, param_spec(), 0, 1, dev)          # world 1: pack / unpack only, no collective
+    assert all(v.is_cuda for v in sd_dev.values())
+    lr = torch.from_numpy(np.random.default_rng(3).random((1, 3, 40, 48), dtype=np.float32)).to(dev)
+    assert torch.equal(FreqFusionHIP(sd_dev, dev)(lr), hip_model(lr))
