@@ -27,7 +27,9 @@ struct TokenLinParams {
   float eps;
 };
 
-template <int ACT, int TL_KS>
+#define TL_TR 36   // floats per row of the transpose patch: 144 B keeps rows 16-byte aligned and ds_*_b128 conflict-free
+
+template <int ACT, int TL_KS, bool VEC4>
 __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
   constexpr int TL_SLOTS = 2 * TL_KS + 1, TL_ROWB = TL_SLOTS * 16, TL_PL = 32 * TL_SLOTS, TL_PIECES = 2 * TL_PL / 64;
   constexpr int TL_TILE_ELEMS = 32 * 16 * TL_KS, KPAD = 16 * TL_KS;
@@ -36,9 +38,9 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
   constexpr int BUFB = 2 * WB;                       // one ring slot (hi + lo)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  float* tr = reinterpret_cast<float*>(smem + 2 * BUFB) + wid * (32 * 33);   // wave-private transpose patch
-  float* xs = reinterpret_cast<float*>(smem + 2 * BUFB + 8 * 32 * 33 * 4) + wid * (32 * FF_XS_ROW);   // wave-private x staging
-  float* Bs = reinterpret_cast<float*>(smem + 2 * BUFB + 8 * 32 * 33 * 4 + 8 * 32 * FF_XS_ROW * 4);   // [NT*32] bias
+  float* tr = reinterpret_cast<float*>(smem + 2 * BUFB) + wid * (32 * TL_TR);   // wave-private transpose patch [token][36]
+  float* xs = reinterpret_cast<float*>(smem + 2 * BUFB + 8 * 32 * TL_TR * 4) + wid * (32 * FF_XS_ROW);   // wave-private x staging
+  float* Bs = reinterpret_cast<float*>(smem + 2 * BUFB + 8 * 32 * TL_TR * 4 + 8 * 32 * FF_XS_ROW * 4);   // [NT*32] bias
   const long long tok0 = (long long)blockIdx.x * 256 + wid * 32;
   const long long tok = tok0 + l31;
   const bool tvalid = tok < p.M;
@@ -117,18 +119,39 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (nt + 1 < p.NT) dma(nt + 1, buf ^ 1);
-    // residuals of this tile are fetched now and consumed after the MFMAs
+    // residuals of this tile are fetched now and consumed after the MFMAs.  vec4 layout (rows 16-byte aligned, N % 4 == 0):
+    // lane = (token row tq = lane >> 3 (+8 per step), channel quad cq4 = lane & 7) -> one float4 per lane and step, i.e.
+    // 8 whole 128-byte row segments per instruction instead of 2 with dword accesses.
     const int col = nt * 32 + l31;
     const bool cok = col < p.N;
     const int cc = cok ? col : 0;
+    const int tq = lane >> 3, c4 = nt * 32 + 4 * (lane & 7);
+    const bool c4ok = c4 < p.N;
     float rv[16];
+    f32x4 rq[4];
+    if (VEC4) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const long long tk = tok0 + 2 * i + hh;
-      const long long tq = tk < p.M ? tk : 0;
-      float r0 = p.res ? p.res[tq * p.ldr + cc] : 0.f;
-      if (p.res2) r0 += p.res2[tq * p.ldr2 + cc] * p.rs2[cc];
-      rv[i] = r0;
+      for (int i = 0; i < 4; ++i) {
+        const long long tk = tok0 + tq + 8 * i;
+        const bool ok = c4ok && tk < p.M;
+        f32x4 r0 = {0.f, 0.f, 0.f, 0.f};
+        if (p.res) { const f32x4 u = *reinterpret_cast<const f32x4*>(p.res + (ok ? tk * p.ldr + c4 : 0)); r0 = ok ? u : r0; }
+        if (p.res2) {
+          const f32x4 u = *reinterpret_cast<const f32x4*>(p.res2 + (ok ? tk * p.ldr2 + c4 : 0));
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.rs2 + (c4ok ? c4 : 0));
+          if (ok) r0 += u * sc;
+        }
+        rq[i] = r0;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const long long tk = tok0 + 2 * i + hh;
+        const long long tqq = tk < p.M ? tk : 0;
+        float r0 = p.res ? p.res[tqq * p.ldr + cc] : 0.f;
+        if (p.res2) r0 += p.res2[tqq * p.ldr2 + cc] * p.rs2[cc];
+        rv[i] = r0;
+      }
     }
     const unsigned char* ap = smem + buf * BUFB + l31 * TL_ROWB + 16 * hh;
     f32x16 acc;
@@ -157,24 +180,48 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue of this tile: act, transpose through the wave's LDS patch, coalesced row-segment stores --------
+    // accumulator register r of lane (l31 = token, hh) is channel (r & 3) + 8 (r >> 2) + 4 hh: four consecutive channels
+    // per r >> 2 -> one ds_write_b128 each
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tr[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * hh] = ff_act_c<ACT, true>(acc[r]);
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v4[e] = ff_act_c<ACT, true>(acc[4 * g + e]);
+      *reinterpret_cast<f32x4*>(tr + l31 * TL_TR + 8 * g + 4 * hh) = v4;
+    }
     // One wait per tile, placed BEFORE this tile's stores: it retires the DMA of tile nt+1 (issued a whole tile ago),
     // this tile's residual loads and the PREVIOUS tile's stores -- so stores always have a full tile to drain
     // (vmcnt counts stores too; waiting right after issuing them would serialise the kernel on HBM write latency).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    float ov[16];
+    if (VEC4) {
+      f32x4 ov[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ov[i] = tr[(2 * i + hh) * 33 + l31] + rv[i];      // 16 LDS reads back to back
-    if (cok) {                                                                        // one exec mask for the whole tile
-      float* op = p.out + (tok0 + hh) * p.ldo + col;
-      if (tok0 + 32 <= p.M) {
+      for (int i = 0; i < 4; ++i) ov[i] = *reinterpret_cast<const f32x4*>(tr + (tq + 8 * i) * TL_TR + 4 * (lane & 7)) + rq[i];
+      if (c4ok) {
+        float* op = p.out + (tok0 + tq) * p.ldo + c4;
+        if (tok0 + 32 <= p.M) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) op[(long long)(2 * i) * p.ldo] = ov[i];
-      } else {
+          for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(op + (long long)(8 * i) * p.ldo) = ov[i];
+        } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (tok0 + 2 * i + hh < p.M) op[(long long)(2 * i) * p.ldo] = ov[i];
+          for (int i = 0; i < 4; ++i)
+            if (tok0 + tq + 8 * i < p.M) *reinterpret_cast<f32x4*>(op + (long long)(8 * i) * p.ldo) = ov[i];
+        }
+      }
+    } else {
+      float ov[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ov[i] = tr[(2 * i + hh) * TL_TR + l31] + rv[i];      // 16 LDS reads back to back
+      if (cok) {                                                                        // one exec mask for the whole tile
+        float* op = p.out + (tok0 + hh) * p.ldo + col;
+        if (tok0 + 32 <= p.M) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) op[(long long)(2 * i) * p.ldo] = ov[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (tok0 + 2 * i + hh < p.M) op[(long long)(2 * i) * p.ldo] = ov[i];
+        }
       }
     }
   }
@@ -197,25 +244,29 @@ extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, lon
   p.x = x; p.out = out; p.gamma = gamma; p.beta = beta; p.w = (const __bf16*)w_tiles; p.bias = bias_padded;
   p.res = res; p.res2 = res2; p.rs2 = res2_scale; p.M = M; p.ldx = ldx; p.ldo = ldo; p.ldr = ldr; p.ldr2 = ldr2;
   p.K = K; p.N = N; p.NT = n_tiles; p.act = act; p.eps = eps;
+  const bool vec4 = (N % 4 == 0) && (ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && (!res || (ldr % 4 == 0 && (((uintptr_t)res) & 15) == 0)) &&
+           (!res2 || (ldr2 % 4 == 0 && (((uintptr_t)res2) & 15) == 0 && (((uintptr_t)res2_scale) & 15) == 0));
   const int ks = kpad / 16;
-  const size_t lds = (size_t)2 * 2 * 32 * (2 * ks + 1) * 16 + (size_t)8 * 32 * 33 * 4 + (size_t)8 * 32 * FF_XS_ROW * 4 + (size_t)n_tiles * 32 * 4;
+  const size_t lds = (size_t)2 * 2 * 32 * (2 * ks + 1) * 16 + (size_t)8 * 32 * TL_TR * 4 + (size_t)8 * 32 * FF_XS_ROW * 4 + (size_t)n_tiles * 32 * 4;
   FF_CHECK_ARG(lds <= 160 * 1024, "ff_token_linear: N too large for the LDS image");
   FF_CHECK_ARG(act == ACT_NONE || act == ACT_GELU, "ff_token_linear: act must be none or gelu");
   const long long nblk = (M + 255) / 256;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_linear: grid too large");
-#define TL_LAUNCH(A, KSV)                                                                                                   \
+#define TL_LAUNCH(A, KSV, V4)                                                                                               \
   do {                                                                                                                      \
     static bool attr_set = false;                                                                                           \
     if (!attr_set) {                                                                                                        \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<A, KSV>),                       \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<A, KSV, V4>),                   \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
       if (e != hipSuccess) { ff_set_error("ff_token_linear: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; } \
       attr_set = true;                                                                                                      \
     }                                                                                                                       \
-    hipLaunchKernelGGL((token_linear_kernel<A, KSV>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);        \
+    hipLaunchKernelGGL((token_linear_kernel<A, KSV, V4>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);    \
   } while (0)
-  if (act == ACT_GELU) { if (ks == 4) TL_LAUNCH(ACT_GELU, 4); else if (ks == 8) TL_LAUNCH(ACT_GELU, 8); else TL_LAUNCH(ACT_GELU, 12); }
-  else { if (ks == 4) TL_LAUNCH(ACT_NONE, 4); else if (ks == 8) TL_LAUNCH(ACT_NONE, 8); else TL_LAUNCH(ACT_NONE, 12); }
+#define TL_LAUNCH_KS(A, V4) do { if (ks == 4) TL_LAUNCH(A, 4, V4); else if (ks == 8) TL_LAUNCH(A, 8, V4); else TL_LAUNCH(A, 12, V4); } while (0)
+  if (act == ACT_GELU) { if (vec4) TL_LAUNCH_KS(ACT_GELU, true); else TL_LAUNCH_KS(ACT_GELU, false); }
+  else { if (vec4) TL_LAUNCH_KS(ACT_NONE, true); else TL_LAUNCH_KS(ACT_NONE, false); }
+#undef TL_LAUNCH_KS
 #undef TL_LAUNCH
   FF_LAUNCH_CHECK("ff_token_linear");
   return FF_OK;

@@ -161,7 +161,7 @@ def test_token_mlp_fused(dev, M):
 
 
 @pytest.mark.parametrize("M,N,ln,act,nres", [(65536, 540, True, None, 0), (1000, 180, False, None, 2), (777, 720, True, "gelu", 0),
-                                            (300, 11, False, "gelu", 0), (256, 180, False, None, 1)])
+                                            (300, 11, False, "gelu", 0), (256, 180, False, None, 1), (500, 182, False, None, 2)])
 def test_token_linear(dev, M, N, ln, act, nres):
     """Token-stationary linear (+LayerNorm prologue, +GELU, +one or two residuals) against the PyTorch fp32 chain."""
     from isr2_amd import ops
