@@ -40,6 +40,7 @@ struct ConvBfParams {
   int act;
   float alpha;
   int shuffle;
+  int vec_out;     // 16-byte epilogue: no shuffle, Cout % 4 == 0, 16-byte aligned out / res rows
 };
 
 #define ROWB 144   // bytes per LDS row: 64 hi + 64 lo + 16 pad
@@ -222,6 +223,53 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16_kernel(ConvBfPar
   auto epilogue = [&](auto ACTC) {
     constexpr int ACT = decltype(ACTC)::value;
     const bool has_res = p.res != nullptr;
+    if (p.vec_out) {
+      // 16-byte form: each 32(m) x 32(n) accumulator tile goes through a wave-private LDS patch (the staging buffers are
+      // idle now) so a lane owns four consecutive channels of one row: float4 residual loads and stores, 8 whole
+      // 128-byte row segments per instruction instead of 2 with dword accesses.
+      float* tr = reinterpret_cast<float*>(smem) + wid * (32 * 36);
+      const int tq = lane >> 3, q4 = 4 * (lane & 7);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wc * TN + j * 32 + l31;
+        const int nc = n < p.Cout ? n : 0;
+        const float bv = p.bias ? p.bias[nc] : 0.f;
+        const float mv = (p.mul ? p.mul[nc] : 1.f) * p.alpha;
+        const int nq = n0 + wc * TN + j * 32 + q4;
+        const bool nqok = nq < p.Cout;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int mb = m0 + wr * TM + i * 32;
+          f32x4 rq[4];
+          long long oo[4];
+          bool ok[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int m = mb + tq + 8 * k;
+            ok[k] = nqok && m < p.M;
+            oo[k] = ok[k] ? (long long)m * p.ldo + nq : 0;
+            f32x4 r0 = {0.f, 0.f, 0.f, 0.f};
+            if (has_res) { const f32x4 u = *reinterpret_cast<const f32x4*>(p.res + (ok[k] ? (long long)m * p.ldr + nq : 0)); r0 = ok[k] ? u : r0; }
+            rq[k] = r0;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            tr[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + l31] = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv;
+          f32x4 ov[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ov[k] = *reinterpret_cast<const f32x4*>(tr + (tq + 8 * k) * 36 + q4) + rq[k];
+          if (nqok && mb + 32 <= p.M) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(p.out + oo[k]) = ov[k];
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (ok[k]) *reinterpret_cast<f32x4*>(p.out + oo[k]) = ov[k];
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int n = n0 + wc * TN + j * 32 + l31;
@@ -331,6 +379,8 @@ extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_
   p.KH = KH; p.KW = KW; p.sy = sy; p.sx = sx; p.py = py; p.px = px;
   p.K = KH * KW * Cin; p.Kp = Kp; p.Cp = Cp; p.M = B * Ho * Wo;
   p.act = act; p.alpha = alpha; p.shuffle = shuffle;
+  p.vec_out = shuffle == 0 && Cout % 4 == 0 && ldo % 4 == 0 && (((uintptr_t)out) & 15) == 0 &&
+              (!res || (ldr % 4 == 0 && (((uintptr_t)res) & 15) == 0));
   const bool vec4 = (Cin % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)in & 15) == 0);
   FF_CHECK_ARG(Cp == 0 || vec4, "ff_conv2d_bf16s: TAP layout needs Cin %% 4 == 0 and 16-byte aligned rows");
   hipStream_t st = (hipStream_t)stream;

@@ -47,6 +47,7 @@ struct TokenMlpParams {
   float eps;
 };
 
+template <bool VEC4>
 __global__ __launch_bounds__(512) void token_mlp_kernel(TokenMlpParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int W1B = W1PL * 16, W2B = W2PL * 16;
@@ -226,8 +227,54 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(TokenMlpParams p) {
   // ---- epilogue: all 96 residual loads first (x fragments are dead, registers are free), then per n-tile a
   // transpose through LDS -> coalesced 128-byte row segments.  (out may alias x as far as the compiler knows: a
   // load placed after a store would be serialised behind it.)
-  float* tr = reinterpret_cast<float*>(smem) + wid * (32 * 33);      // per-wave [token][33] inside the (now idle) W images
   const long long tok0 = (long long)blockIdx.x * 256 + wid * 32;
+  if (VEC4) {
+    // 16-byte form: the accumulator's four consecutive channels per r >> 2 go to the patch as one ds_write_b128, a lane
+    // then owns (token row lane >> 3 (+8 per step), channel quad lane & 7): one float4 residual load and one float4
+    // store per step = 8 whole 128-byte row segments per instruction (2 with dword accesses)
+    float* tr = reinterpret_cast<float*>(smem) + wid * (32 * 36);    // per-wave [token][36] inside the (now idle) W images
+    const int tq = lane >> 3, q4 = 4 * (lane & 7);
+    f32x4 rq[6][4];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const int c4 = n * 32 + q4;
+      const bool cok = c4 < p.N;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.b2 + (cok ? c4 : 0));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long tk = tok0 + tq + 8 * i;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p.x + (tk < p.M ? tk : 0) * p.ldx + (cok ? c4 : 0));
+        rq[n][i] = u + b4;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = oacc[n][4 * g + e];
+        *reinterpret_cast<f32x4*>(tr + l31 * 36 + 8 * g + 4 * hh) = v4;
+      }
+      f32x4 ov[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ov[i] = *reinterpret_cast<const f32x4*>(tr + (tq + 8 * i) * 36 + q4) + rq[n][i];
+      const int c4 = n * 32 + q4;
+      if (c4 < p.N) {
+        float* op = p.out + (tok0 + tq) * p.ldo + c4;
+        if (tok0 + 32 <= p.M) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(op + (long long)(8 * i) * p.ldo) = ov[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (tok0 + tq + 8 * i < p.M) *reinterpret_cast<f32x4*>(op + (long long)(8 * i) * p.ldo) = ov[i];
+        }
+      }
+    }
+    return;
+  }
+  float* tr = reinterpret_cast<float*>(smem) + wid * (32 * 33);      // per-wave [token][33] inside the (now idle) W images
   float rv[6][16];
 #pragma unroll
   for (int n = 0; n < 6; ++n) {
@@ -273,17 +320,24 @@ extern "C" int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long l
   TokenMlpParams p;
   p.x = x; p.out = out; p.gamma = gamma; p.beta = beta; p.w = (const __bf16*)w_tiles;
   p.b1 = b1_padded; p.b2 = b2; p.M = M; p.ldx = ldx; p.ldo = ldo; p.K = K; p.N = N; p.HT = hidden_tiles; p.eps = eps;
+  const bool vec4 = (N % 4 == 0) && (ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && ((((uintptr_t)b2) & 15) == 0);
   const size_t lds = (size_t)(2 * W1PL + 2 * W2PL) * 16 + (size_t)8 * 32 * XLROWB + (size_t)hidden_tiles * 32 * 4;
   FF_CHECK_ARG(lds <= 160 * 1024, "ff_token_mlp: hidden too large for the LDS image");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { ff_set_error("ff_token_mlp: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
-    attr_set = true;
-  }
   const long long nblk = (M + 255) / 256;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_mlp: grid too large");
-  hipLaunchKernelGGL(token_mlp_kernel, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+#define TM_LAUNCH(V4)                                                                                                      \
+  do {                                                                                                                     \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_mlp_kernel<V4>),                             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
+      if (e != hipSuccess) { ff_set_error("ff_token_mlp: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; } \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    hipLaunchKernelGGL(token_mlp_kernel<V4>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);                \
+  } while (0)
+  if (vec4) TM_LAUNCH(true); else TM_LAUNCH(false);
+#undef TM_LAUNCH
   FF_LAUNCH_CHECK("ff_token_mlp");
   return FF_OK;
 }
