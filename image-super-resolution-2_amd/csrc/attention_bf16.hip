@@ -26,6 +26,7 @@ struct AttnBfParams {
   int heads, d;
   float scale;
   int nwx, nwy;
+  int vec_out;     // float2 output rows: d, o_off, ldo even and out 8-byte aligned
 };
 
 #define AKC 128            // keys per chunk
@@ -238,6 +239,26 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
+  if (p.vec_out) {
+    // O^T sits with the query in the lane and 16 head channels in registers: stored directly, every instruction would
+    // scatter 64 dwords over 32 token rows.  The K/V staging buffers are idle after the loop's last barrier, so each wave
+    // transposes its 32 x 32 tile through a private patch and writes 120-byte row segments as float2 (16 lanes per query).
+    float* tr = reinterpret_cast<float*>(smem) + wid * (32 * 34);
+    int* tokq = reinterpret_cast<int*>(smem + 8 * 32 * 34 * 4) + wid * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tr[l31 * 34 + (r & 3) + 8 * (r >> 2) + 4 * hh] = o[r] * inv;
+    if (hh == 0) tokq[l31] = qvalid ? (int)qtok : -1;
+    const int pr = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = (lane >> 4) + 4 * i;
+      const int tk = tokq[q];
+      const float2 v = *reinterpret_cast<const float2*>(tr + q * 34 + 2 * pr);
+      if (tk >= 0 && 2 * pr < p.d)
+        *reinterpret_cast<float2*>(p.out + (long long)tk * p.ldo + p.o_off + head * p.d + 2 * pr) = v;
+    }
+    return;
+  }
   if (qvalid) {
     float* op = p.out + qtok * p.ldo + p.o_off + head * p.d;
 #pragma unroll
@@ -267,6 +288,7 @@ extern "C" int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_
   p.B = B; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.wh = wh; p.ww = ww; p.kh = kh; p.kw = kw;
   p.sh = shift_h; p.sw = shift_w; p.use_mask = use_mask; p.heads = heads; p.d = d; p.scale = scale;
   p.nwx = Wp / ww; p.nwy = Hp / wh;
+  p.vec_out = (d % 2 == 0) && (o_off % 2 == 0) && (ldo % 2 == 0) && ((((uintptr_t)out) & 7) == 0);
   p.nkpad = (kh * kw + AKC - 1) / AKC * AKC;
   const long long nblk = (long long)B * p.nwx * p.nwy * heads;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_window_attn_bf16s: grid too large");
