@@ -27,6 +27,7 @@ struct AttnBfParams {
   float scale;
   int nwx, nwy;
   int vec_out;     // float2 output rows: d, o_off, ldo even and out 8-byte aligned
+  int vec_q;       // float2 query loads: d, q_off, ldq even and qkv 8-byte aligned
 };
 
 #define AKC 128            // keys per chunk
@@ -71,15 +72,31 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
   }
   bf16x8 qh[2], ql[2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < 2; ++s) {
+    float qf[8];
+    if (p.vec_q) {                                  // 8-byte loads: the head's channels start on an even float
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const int dd = 16 * s + 8 * hh + j;
+        const bool ok = qvalid && dd < p.d;
+        const float2 u = *reinterpret_cast<const float2*>(p.qkv + (ok ? qtok * p.ldq + p.q_off + head * p.d + dd : 0));
+        qf[j] = ok ? u.x * p.scale : 0.f;
+        qf[j + 1] = ok ? u.y * p.scale : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int dd = 16 * s + 8 * hh + j;
+        qf[j] = (qvalid && dd < p.d) ? p.qkv[qtok * p.ldq + p.q_off + head * p.d + dd] * p.scale : 0.f;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int dd = 16 * s + 8 * hh + j;
-      const float f = (qvalid && dd < p.d) ? p.qkv[qtok * p.ldq + p.q_off + head * p.d + dd] * p.scale : 0.f;
-      const __bf16 h = (__bf16)f;
+      const __bf16 h = (__bf16)qf[j];
       qh[s][j] = h;
-      ql[s][j] = (__bf16)(f - (float)h);
+      ql[s][j] = (__bf16)(qf[j] - (float)h);
     }
+  }
 
   f32x16 o;
 #pragma unroll
@@ -87,7 +104,6 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
   float m_run = -INFINITY, l_run = 0.f;
   const float LOG2E = 1.4426950408889634f;
 
-  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.biasT), 0, p.heads * nk * 256 * 4, 0x00020000);
   const int nchunks = (nk + AKC - 1) / AKC;
   // ---- per-block key tables: token index (or -1 for the zero keys outside the image) and mask region of every key ------
   for (int kidx = tid; kidx < nchunks * AKC; kidx += 512) {
@@ -133,22 +149,30 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
     // ---- bias of this chunk -> accumulators (C-in of the QK^T MFMAs) ---------------------------------------------
     f32x16 st[4];
     {
-      const int cbase = (int)(((long long)head * nk + (long long)c * AKC) * 256 * 4);
-      const int voff = (4 * hh * 256 + qi) * 4;
+      // biasQ is quad-interleaved [heads][nk/4][256 queries][4 keys]: accumulator registers 4g..4g+3 of a lane are four
+      // consecutive keys of its query, i.e. ONE 16-byte load (16 loads per chunk and lane instead of 64; a half-wave
+      // reads 512 contiguous bytes).
+      const float* bbase = p.biasT + ((long long)head * nk + (long long)c * AKC) * 256;      // wave-uniform
+      const int lo = hh * 1024 + 4 * qi;                                                      // floats: key half + query
       if (full) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            st[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, voff, cbase + (t * 32 + (r & 3) + 8 * (r >> 2)) * 1024, 0));
-      } else {
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(bbase + (t * 32 + 8 * g) * 256 + lo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[t][4 * g + e] = u[e];
+          }
+      } else {                           // ragged last chunk: clamp the key quad into the table (those keys are masked below)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kc = t * 32 + (r & 3) + 8 * (r >> 2);
-            const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(brsrc, voff, cbase + kc * 1024, 0);
-            st[t][r] = (c * AKC + kc + 4 * hh < nk) ? __builtin_bit_cast(float, u) : 0.f;
+          for (int g = 0; g < 4; ++g) {
+            int k0 = c * AKC + t * 32 + 8 * g + 4 * hh;
+            k0 = k0 < nk ? k0 : nk - 4;
+            const f32x4 u = *reinterpret_cast<const f32x4*>(p.biasT + ((long long)head * nk + k0) * 256 + 4 * qi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[t][4 * g + e] = u[e];
           }
       }
     }
@@ -275,6 +299,7 @@ extern "C" int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_
                                     int nterms, void* stream) {
   FF_CHECK_ARG(qkv && out && biasT, "ff_window_attn_bf16s: null pointer");
   FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_window_attn_bf16s: nterms must be 1 or 3");
+  FF_CHECK_ARG((kh * kw) % 4 == 0 && (((uintptr_t)biasT) & 15) == 0, "ff_window_attn_bf16s: the quad-interleaved bias table needs kh*kw %% 4 == 0 and 16-byte alignment");
   FF_CHECK_ARG(wh * ww == 256, "ff_window_attn_bf16s: query window must hold 256 tokens (got %dx%d)", wh, ww);
   FF_CHECK_ARG(d > 0 && d <= 32 && heads > 0, "ff_window_attn_bf16s: head dim %d unsupported (<=32)", d);
   FF_CHECK_ARG(kh >= wh && kw >= ww && (kh - wh) % 2 == 0 && (kw - ww) % 2 == 0, "ff_window_attn_bf16s: bad key window");
@@ -288,6 +313,7 @@ extern "C" int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_
   p.B = B; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.wh = wh; p.ww = ww; p.kh = kh; p.kw = kw;
   p.sh = shift_h; p.sw = shift_w; p.use_mask = use_mask; p.heads = heads; p.d = d; p.scale = scale;
   p.nwx = Wp / ww; p.nwy = Hp / wh;
+  p.vec_q = (d % 2 == 0) && (q_off % 2 == 0) && (ldq % 2 == 0) && ((((uintptr_t)qkv) & 7) == 0);
   p.vec_out = (d % 2 == 0) && (o_off % 2 == 0) && (ldo % 2 == 0) && ((((uintptr_t)out) & 7) == 0);
   p.nkpad = (kh * kw + AKC - 1) / AKC * AKC;
   const long long nblk = (long long)B * p.nwx * p.nwy * heads;

@@ -265,7 +265,12 @@ def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int,
                                        win[1], kwin[0], kwin[1], shift[0], shift[1], int(use_mask), heads, d, float(scale),
                                        _stream()))
     else:
-        _lib.check(_L().ff_window_attn_bf16s(qp, ldq, q_off, k_off, v_off, op, ldo, o_off, biasT.data_ptr(), B, H, W, Hp, Wp,
+        bq = getattr(biasT, "_ff_quad", None)
+        if bq is None:                              # load-time relayout, cached on the table
+            from . import prep as _prep
+            bq = _prep.quad_bias(biasT)
+            biasT._ff_quad = bq
+        _lib.check(_L().ff_window_attn_bf16s(qp, ldq, q_off, k_off, v_off, op, ldo, o_off, bq.data_ptr(), B, H, W, Hp, Wp,
                                              win[0], win[1], kwin[0], kwin[1], shift[0], shift[1], int(use_mask), heads, d,
                                              float(scale), 1 if _GEMM_MODE == "bf16" else 3, _stream()))
     nwin = B * (Hp // win[0]) * (Wp // win[1])

@@ -65,6 +65,13 @@ def pack_token_mlp(w1: T, b1: T, w2: T, b2: T) -> dict:
     return dict(ht=ht, K=K, N=N, w=tiles, b1=b1p.contiguous(), b2=b2.contiguous())
 
 
+def quad_bias(biasT: T) -> T:
+    """[heads][nk][256] key-major attention bias -> quad-interleaved [heads][nk/4][256][4] for ff_window_attn_bf16s."""
+    heads, nk, nq = biasT.shape
+    assert nk % 4 == 0 and nq == 256
+    return biasT.reshape(heads, nk // 4, 4, nq).permute(0, 1, 3, 2).contiguous()
+
+
 def halo_bn(cout: int) -> int:
     """Output channels per workgroup of ff_conv3x3_halo: least padding, ties to the wider tile."""
     if cout <= 32:

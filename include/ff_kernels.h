@@ -70,7 +70,10 @@ int ff_window_attn(const float* qkv, int ldq, int q_off, int k_off, int v_off, f
                    int shift_h, int shift_w, int use_mask, int heads, int d, float scale, void* stream);
 
 /* Same attention on the bf16 matrix cores with split operands (csrc/attention_bf16.hip): nterms 3 = fp32-grade
- * (hi*hi + lo*hi + hi*lo for both QK^T and PV), 1 = plain bf16 operands.  Same arguments otherwise. */
+ * (hi*hi + lo*hi + hi*lo for both QK^T and PV), 1 = plain bf16 operands.  Same arguments otherwise, except that the
+ * bias table is quad-interleaved: biasT[head][key / 4][query][key % 4] (= the table of ff_window_attn reshaped
+ * [heads][nk/4][4][256] and permuted (0,1,3,2); prep.quad_bias), so four consecutive keys of a query are one 16-byte load.
+ * kh*kw % 4 == 0. */
 int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_off, int v_off, float* out, int ldo, int o_off,
                          const float* biasT, int B, int H, int W, int Hp, int Wp, int wh, int ww, int kh, int kw,
                          int shift_h, int shift_w, int use_mask, int heads, int d, float scale, int nterms, void* stream);
