@@ -23,13 +23,18 @@ struct HaloParams {
 #define HX_ROW 272
 #define HX_W 18
 
-template <int WM, int WN, int MI, int NI>
+// WK = input channels per weight tile (64: one tile per (chunk, tap); 32: two).  The 192-channel configuration uses
+// 16x16-pixel workgroups (weights are re-streamed per workgroup: 256 pixels per fetch halve the L2 traffic that bounds
+// the 128-pixel form) and 32-channel weight tiles so that the 88 KB input tile and the ring still fit in 160 KB.
+template <int WM, int WN, int MI, int NI, int WK, int ACT>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
   static_assert(WM * WN == 4, "four waves");
   constexpr int TH = WM * MI * 2, NPX = (TH + 2) * HX_W, NPASS = (NPX + 15) / 16;
   constexpr int BN = WN * NI * 32, TN = NI * 32;
   constexpr int XBYTES = NPX * HX_ROW;
-  constexpr int WPIECES = (BN * HX_ROW + 1023) / 1024, WSLOT = WPIECES * 1024;
+  constexpr int WROW = WK * 4 + 16, NH = 64 / WK, KSTEPS = WK / 16;
+  constexpr bool XPREF = MI * NI <= 6;        // prefetch the next chunk's input rows into registers during tap 7
+  constexpr int WPIECES = (BN * WROW + 1023) / 1024, WSLOT = WPIECES * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Xs = smem;
   unsigned char* Ws = smem + XBYTES;
@@ -48,8 +53,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
   const int y0 = ty * TH, x0 = tx * 16;
   const int n0 = nb * BN;
 
-  // ---- weight ring: tile index T = chunk*9 + tap, image [nblk][nchunk*9][WSLOT] --------------------------------
-  const unsigned char* wimg = p.w + (long long)nb * p.nchunk * 9 * WSLOT;
+  // ---- weight ring: tile index T = (chunk*9 + tap)*NH + half, image [nblk][nchunk*9*NH][WSLOT] -------------------
+  const unsigned char* wimg = p.w + (long long)nb * p.nchunk * 9 * NH * WSLOT;
   auto dma = [&](int T, int slot) {
     const unsigned char* src = wimg + (long long)T * WSLOT + lane * 16;
 #pragma unroll
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
                                          (__attribute__((address_space(3))) void*)(Ws + slot * WSLOT + pc * 1024), 16, 0, 0);
     }
   };
-  const int ntiles = p.nchunk * 9;
+  const int ntiles = p.nchunk * 9 * NH;
   dma(0, 0);
 
   // ---- input halo staging: 16 lanes (float4 each) per pixel, 16 pixels per pass ---------------------------------
@@ -120,52 +125,55 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll
   for (int i = 0; i < MI; ++i) aoff[i] = (((wr * MI + i) * 2 + (l31 >> 4)) * HX_W + (l31 & 15)) * HX_ROW + 16 * hh;
 #pragma unroll
-  for (int j = 0; j < NI; ++j) boff[j] = (wc * TN + j * 32 + l31) * HX_ROW + 16 * hh;
+  for (int j = 0; j < NI; ++j) boff[j] = (wc * TN + j * 32 + l31) * WROW + 16 * hh;
 
   int T = 0;
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-    for (int tap = 0; tap < 9; ++tap, ++T) {
-      // own DMA pieces of tile T (and any prefetched input rows) have landed; the barrier then makes every wave's
-      // pieces and the staged input tile visible, and guarantees slot (T+1)&1 is no longer being read
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (T + 1 < ntiles) dma(T + 1, (T + 1) & 1);
-      if (tap == 7 && chunk + 1 < p.nchunk) load_x(chunk + 1);
+    for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap - 3 * dy;
       const unsigned char* xa = Xs + (dy * HX_W + dx) * HX_ROW;
-      const unsigned char* wb = Ws + (T & 1) * WSLOT;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+      for (int half = 0; half < NH; ++half, ++T) {
+        // own DMA pieces of tile T (and any prefetched input rows) have landed; the barrier then makes every wave's
+        // pieces and the staged input tile visible, and guarantees slot (T+1)&1 is no longer being read
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (T + 1 < ntiles) dma(T + 1, (T + 1) & 1);
+        if (XPREF && tap == 7 && half == NH - 1 && chunk + 1 < p.nchunk) load_x(chunk + 1);
+        const unsigned char* wb = Ws + (T & 1) * WSLOT;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          ah[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * s);
-          al[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * s + 128);
-        }
+        for (int s = 0; s < KSTEPS; ++s) {
+          bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          bh[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s);
-          bl[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s + 128);
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
+          for (int i = 0; i < MI; ++i) {
+            ah[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * (half * KSTEPS + s));
+            al[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * (half * KSTEPS + s) + 128);
+          }
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            bh[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s);
+            bl[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s + WK * 2);
           }
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
       }
     }
     if (chunk + 1 < p.nchunk) {
       __syncthreads();                 // every wave is done reading this chunk's input tile
+      if (!XPREF) load_x(chunk + 1);   // big-accumulator configuration: no registers to hold the prefetch across the taps
       store_x();                       // (made visible by the barrier at the top of the next tap)
     }
   }
 
   // ---- epilogue: lane = output channel column, 16 pixels per m-tile ---------------------------------------------
-  auto epilogue = [&](auto ACTC) {
-    constexpr int ACT = decltype(ACTC)::value;
+  {
     const bool has_res = p.res != nullptr;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -203,16 +211,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
           for (int r = 0; r < 16; ++r)
             if (okp[r]) p.out[oidx[r]] = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
         }
+        __builtin_amdgcn_sched_barrier(0);   // one tile at a time: do not interleave the address / residual work of all MI*NI tiles
       }
     }
-  };
-  FF_DISPATCH_ACT(p.act, epilogue)
+  }
 }
 
-template <int WM, int WN, int MI, int NI>
+template <int WM, int WN, int MI, int NI, int WK>
 static int launch_halo(HaloParams& p, hipStream_t st) {
   constexpr int TH = WM * MI * 2, NPX = (TH + 2) * HX_W, BN = WN * NI * 32;
-  constexpr int WSLOT = ((BN * HX_ROW + 1023) / 1024) * 1024;
+  constexpr int WSLOT = ((BN * (WK * 4 + 16) + 1023) / 1024) * 1024;
   constexpr size_t lds = (size_t)NPX * HX_ROW + 2 * WSLOT;
   static_assert(lds <= 160 * 1024, "LDS budget");
   p.tiles_x = (p.W + 15) / 16;
@@ -220,14 +228,20 @@ static int launch_halo(HaloParams& p, hipStream_t st) {
   p.nblk = (p.Cout + BN - 1) / BN;
   const long long nblocks = (long long)p.tiles_x * p.tiles_y * p.B * p.nblk;
   if (nblocks >= (1LL << 31)) { ff_set_error("ff_conv3x3_halo: grid too large"); return FF_ERR_ARG; }
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, MI, NI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { ff_set_error("ff_conv3x3_halo: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return FF_ERR_LAUNCH; }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, MI, NI>), dim3((unsigned)nblocks), dim3(256), lds, st, p);
+  bool attr_failed = false;
+  auto go = [&](auto A) {                      // the activation is a template parameter: one epilogue per kernel
+    constexpr int ACT = decltype(A)::value;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, MI, NI, WK, ACT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { ff_set_error("ff_conv3x3_halo: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); attr_failed = true; return; }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, MI, NI, WK, ACT>), dim3((unsigned)nblocks), dim3(256), lds, st, p);
+  };
+  FF_DISPATCH_ACT(p.act, go);
+  if (attr_failed) return FF_ERR_LAUNCH;
   FF_LAUNCH_CHECK("ff_conv3x3_halo");
   return FF_OK;
 }
@@ -235,8 +249,9 @@ static int launch_halo(HaloParams& p, hipStream_t st) {
 // bytes of the weight image prep.pack_conv3x3_halo must produce for (Cout, Cin, bn)
 extern "C" long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn) {
   if (Cout <= 0 || Cin <= 0 || (bn != 32 && bn != 64 && bn != 128 && bn != 192)) return -1;
-  const long long slot = ((long long)bn * HX_ROW + 1023) / 1024 * 1024;
-  return (long long)((Cout + bn - 1) / bn) * ((Cin + 63) / 64) * 9 * slot;
+  const int wk = bn == 192 ? 32 : 64;                        // channels per weight tile (see launch_halo)
+  const long long slot = ((long long)bn * (wk * 4 + 16) + 1023) / 1024 * 1024;
+  return (long long)((Cout + bn - 1) / bn) * ((Cin + 63) / 64) * 9 * (64 / wk) * slot;
 }
 
 extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const float* bias, const float* mul,
@@ -256,10 +271,10 @@ extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int 
   p.nchunk = (Cin + 63) / 64; p.act = act; p.alpha = alpha; p.shuffle = shuffle;
   hipStream_t st = (hipStream_t)stream;
   switch (bn) {
-    case 32: return launch_halo<4, 1, 2, 1>(p, st);    // 16x16 pixels x 32 channels
-    case 64: return launch_halo<4, 1, 2, 2>(p, st);    // 16x16 pixels x 64
-    case 128: return launch_halo<2, 2, 2, 2>(p, st);   //  8x16 pixels x 128
-    case 192: return launch_halo<2, 2, 2, 3>(p, st);   //  8x16 pixels x 192
+    case 32: return launch_halo<4, 1, 2, 1, 64>(p, st);    // 16x16 pixels x 32 channels
+    case 64: return launch_halo<4, 1, 2, 2, 64>(p, st);    // 16x16 pixels x 64
+    case 128: return launch_halo<2, 2, 2, 2, 64>(p, st);   //  8x16 pixels x 128
+    case 192: return launch_halo<2, 2, 4, 3, 32>(p, st);   // 16x16 pixels x 192, 32-channel weight tiles
     default: ff_set_error("ff_conv3x3_halo: bn must be 32, 64, 128 or 192"); return FF_ERR_ARG;
   }
 }

@@ -81,20 +81,24 @@ def halo_bn(cout: int) -> int:
 
 def pack_conv3x3_halo(wp: T, cin: int, bn: int) -> T:
     """Weight image of ff_conv3x3_halo from a packed 3x3 weight [Cout, 9*cin] (tap-major, pack_conv):
-    bf16 [nblk][nchunk][9][bn rows x (64 hi | 64 lo | 8 pad)] with every (nblk, chunk, tap) record padded to 1 KiB."""
+    bf16 [nblk][nchunk][9][64/wk][bn rows x (wk hi | wk lo | 8 pad)], every record padded to 1 KiB; wk = channels per
+    weight tile = 32 for bn 192 (16x16-pixel workgroups), 64 otherwise."""
     cout = wp.shape[0]
     assert wp.shape[1] == 9 * cin
+    wk = 32 if bn == 192 else 64
+    nh = 64 // wk
     nblk, nchunk = -(-cout // bn), -(-cin // 64)
     w = torch.zeros(nblk * bn, 9, nchunk * 64, device=wp.device)
     w[:cout, :, :cin] = wp.reshape(cout, 9, cin)
     hi = w.to(torch.bfloat16)
     lo = (w - hi.float()).to(torch.bfloat16)
-    rows = torch.zeros(nblk, nchunk, 9, bn, 136, device=wp.device, dtype=torch.bfloat16)
-    rows[..., :64] = hi.reshape(nblk, bn, 9, nchunk, 64).permute(0, 3, 2, 1, 4)
-    rows[..., 64:128] = lo.reshape(nblk, bn, 9, nchunk, 64).permute(0, 3, 2, 1, 4)
-    slot = (bn * 272 + 1023) // 1024 * 1024
-    img = torch.zeros(nblk * nchunk * 9, slot // 2, device=wp.device, dtype=torch.bfloat16)
-    img[:, :bn * 136] = rows.reshape(nblk * nchunk * 9, bn * 136)
+    rows = torch.zeros(nblk, nchunk, 9, nh, bn, 2 * wk + 8, device=wp.device, dtype=torch.bfloat16)
+    rows[..., :wk] = hi.reshape(nblk, bn, 9, nchunk, nh, wk).permute(0, 3, 2, 4, 1, 5)
+    rows[..., wk:2 * wk] = lo.reshape(nblk, bn, 9, nchunk, nh, wk).permute(0, 3, 2, 4, 1, 5)
+    rec = bn * (2 * wk + 8)
+    slot = (rec * 2 + 1023) // 1024 * 1024
+    img = torch.zeros(nblk * nchunk * 9 * nh, slot // 2, device=wp.device, dtype=torch.bfloat16)
+    img[:, :rec] = rows.reshape(nblk * nchunk * 9 * nh, rec)
     return img.contiguous()
 
 
