@@ -196,7 +196,7 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
                                   _stream()))
     elif (_HALO and _GEMM_MODE == "bf16x3" and (KH, KW) == (3, 3) and tuple(stride) == (1, 1) and tuple(pad) == (1, 1)
           and not dynamic_w and Cin >= 32 and Cin % 4 == 0 and ldi % 4 == 0 and xp % 16 == 0
-          and (Cout <= 64 or Cin >= 128 or _HALO_ALL)        # measured (profiles/r01_conv3x3_halo_vs_igemm.txt): wins there, ties / loses for 64 -> 180..256
+          and (Cout <= 64 or Cin >= 128 or 128 < Cout <= 192 or _HALO_ALL)   # measured (profiles/r01_conv3x3_halo_vs_igemm.txt); 64 -> 256 ties
           and H * W >= 1024 and xp != op and B * H * W * ldi < 2 ** 31):
         img = getattr(w, "_ff_halo", None)
         if img is None:

@@ -82,7 +82,7 @@ def halo_bn(cout: int) -> int:
 def pack_conv3x3_halo(wp: T, cin: int, bn: int) -> T:
     """Weight image of ff_conv3x3_halo from a packed 3x3 weight [Cout, 9*cin] (tap-major, pack_conv):
     bf16 [nblk][nchunk][9][64/wk][bn rows x (wk hi | wk lo | 8 pad)], every record padded to 1 KiB; wk = channels per
-    weight tile = 32 for bn 192 (16x16-pixel workgroups), 64 otherwise."""
+    weight tile = 32 for bn 192, 64 otherwise (csrc/conv3x3_halo.hip launch table)."""
     cout = wp.shape[0]
     assert wp.shape[1] == 9 * cin
     wk = 32 if bn == 192 else 64
