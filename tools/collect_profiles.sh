@@ -5,7 +5,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
-mkdir -p $O && cd $R
+rm -rf $O && mkdir -p $O && cd $R
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo "[collect] bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ms -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats_ms.err || exit 1
