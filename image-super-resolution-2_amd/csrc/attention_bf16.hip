@@ -16,6 +16,8 @@ struct AttnBfParams {
   const float* qkv;
   float* out;
   const float* biasT;
+  const float* rel;      // optional compact relative-position table [heads][(2wh-1)*(2ww-1)] (NULL: use biasT)
+  int rel_w, rel_n, lkw;  // 2ww-1, table entries per head, log2(kw)
   int ldq, ldo;
   int q_off, k_off, v_off, o_off;
   int B, H, W, Hp, Wp;
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
   unsigned char* Vl = Vh + 32 * VROWB;
   int* ktok = reinterpret_cast<int*>(Vl + 32 * VROWB);   // [nchunks*AKC] token index of every key (or -1: zero key)
   int* kregAll = ktok + p.nkpad;                         // [nchunks*AKC] shift-region id of every key
+  float* Tl = reinterpret_cast<float*>(kregAll + p.nkpad);   // [rel_n] this head's relative-position table (rel path)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -125,6 +128,8 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
     ktok[kidx] = tk;
     kregAll[kidx] = rid;
   }
+  if (p.rel)
+    for (int i = tid; i < p.rel_n; i += 512) Tl[i] = p.rel[(long long)head * p.rel_n + i];
   __syncthreads();
   // only windows in the last window row / column contain more than one shift region (mask is all zero elsewhere)
   const bool blk_mask = p.use_mask && (wy == p.nwy - 1 || wx == p.nwx - 1);
@@ -152,6 +157,20 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
       // biasQ is quad-interleaved [heads][nk/4][256 queries][4 keys]: accumulator registers 4g..4g+3 of a lane are four
       // consecutive keys of its query, i.e. ONE 16-byte load (16 loads per chunk and lane instead of 64; a half-wave
       // reads 512 contiguous bytes).
+      if (p.rel) {
+        // Relative-position bias gathered from the head's (2wh-1) x (2ww-1) table in LDS (3.8 KB) instead of streaming the
+        // expanded [keys][queries] table (256 KB per head and window, 400 MB per launch from L2 / Infinity Cache):
+        //   bias[q][k] = T[(qy - ky + wh - 1) * (2ww - 1) + (qx - kx + ww - 1)]        (hat_arch.py:882-899, dat_arch.py:300-318)
+        // = lane part (query coordinates, key-column half 4 hh) + wave-uniform part per register (ky, kx of the key).
+        const int lane_base = (qi / p.ww + p.wh - 1) * p.rel_w + (qi % p.ww) - 4 * hh + p.ww - 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key0 = c * AKC + t * 32 + (r & 3) + 8 * (r >> 2);        // uniform; lane half hh adds 4 to kx
+            st[t][r] = Tl[lane_base - (key0 >> p.lkw) * p.rel_w - (key0 & (p.kw - 1))];
+          }
+      } else {
       const float* bbase = p.biasT + ((long long)head * nk + (long long)c * AKC) * 256;      // wave-uniform
       const int lo = hh * 1024 + 4 * qi;                                                      // floats: key half + query
       if (full) {
@@ -174,6 +193,7 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) st[t][4 * g + e] = u[e];
           }
+      }
       }
     }
     // ---- stage K (row-major) and V (transposed, bit-2/3 key permutation) of this chunk from the prefetched registers
@@ -296,10 +316,11 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
 extern "C" int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_off, int v_off, float* out, int ldo,
                                     int o_off, const float* biasT, int B, int H, int W, int Hp, int Wp, int wh, int ww,
                                     int kh, int kw, int shift_h, int shift_w, int use_mask, int heads, int d, float scale,
-                                    int nterms, void* stream) {
-  FF_CHECK_ARG(qkv && out && biasT, "ff_window_attn_bf16s: null pointer");
+                                    int nterms, const float* rel_table, void* stream) {
+  FF_CHECK_ARG(qkv && out && (biasT || rel_table), "ff_window_attn_bf16s: null pointer");
   FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_window_attn_bf16s: nterms must be 1 or 3");
-  FF_CHECK_ARG((kh * kw) % 4 == 0 && (((uintptr_t)biasT) & 15) == 0, "ff_window_attn_bf16s: the quad-interleaved bias table needs kh*kw %% 4 == 0 and 16-byte alignment");
+  FF_CHECK_ARG(rel_table || ((kh * kw) % 4 == 0 && (((uintptr_t)biasT) & 15) == 0), "ff_window_attn_bf16s: the quad-interleaved bias table needs kh*kw %% 4 == 0 and 16-byte alignment");
+  FF_CHECK_ARG(!rel_table || (kh == wh && kw == ww && (kw & (kw - 1)) == 0 && kw >= 8), "ff_window_attn_bf16s: the relative-position table needs keys == query window and a power-of-two window width >= 8");
   FF_CHECK_ARG(wh * ww == 256, "ff_window_attn_bf16s: query window must hold 256 tokens (got %dx%d)", wh, ww);
   FF_CHECK_ARG(d > 0 && d <= 32 && heads > 0, "ff_window_attn_bf16s: head dim %d unsupported (<=32)", d);
   FF_CHECK_ARG(kh >= wh && kw >= ww && (kh - wh) % 2 == 0 && (kw - ww) % 2 == 0, "ff_window_attn_bf16s: bad key window");
@@ -309,6 +330,8 @@ extern "C" int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_
   FF_CHECK_ARG(!use_mask || (shift_h > 0 && shift_w > 0), "ff_window_attn_bf16s: mask needs a shift");
   AttnBfParams p;
   p.qkv = qkv; p.out = out; p.biasT = biasT; p.ldq = ldq; p.ldo = ldo;
+  p.rel = rel_table; p.rel_w = 2 * ww - 1; p.rel_n = (2 * wh - 1) * (2 * ww - 1); p.lkw = 0;
+  while ((1 << p.lkw) < kw) ++p.lkw;
   p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.o_off = o_off;
   p.B = B; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.wh = wh; p.ww = ww; p.kh = kh; p.kw = kw;
   p.sh = shift_h; p.sw = shift_w; p.use_mask = use_mask; p.heads = heads; p.d = d; p.scale = scale;
@@ -319,7 +342,8 @@ extern "C" int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_
   const long long nblk = (long long)B * p.nwx * p.nwy * heads;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_window_attn_bf16s: grid too large");
   FF_CHECK_ARG((long long)B * H * W < (1LL << 31), "ff_window_attn_bf16s: too many tokens");
-  const size_t lds = (size_t)2 * AKC * KROWB + (size_t)2 * 32 * VROWB + (size_t)2 * p.nkpad * 4;
+  const size_t lds = (size_t)2 * AKC * KROWB + (size_t)2 * 32 * VROWB + (size_t)2 * p.nkpad * 4 + (rel_table ? (size_t)p.rel_n * 4 : 0);
+  FF_CHECK_ARG(lds <= 64 * 1024, "ff_window_attn_bf16s: window too large for the LDS image");
   if (nterms == 3)
     hipLaunchKernelGGL(window_attn_bf16_kernel<3>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
   else

@@ -55,6 +55,12 @@ def _fast() -> bool:
 
 
 # =============================================================================================== HAT
+# Gathering the attention bias from the compact relative-position table in LDS removes the 400 MB / launch bias stream but
+# measured SLOWER on MI355X (120 vs 108 us per launch: the kernel is issue / LDS bound, not bandwidth bound), so the
+# expanded quad-interleaved table stays the default; FF_REL_BIAS=1 selects the gather.
+_REL_BIAS = os.environ.get("FF_REL_BIAS", "0") == "1"
+
+
 def _rel_index_sa(ws: int) -> T:
     ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
     yy, xx = ys.reshape(-1), xs.reshape(-1)
@@ -96,7 +102,7 @@ class HatHIP:
                 q = f"layers.{g}.residual_group.blocks.{b}."
                 tbl = w(q + "attn.relative_position_bias_table")
                 bias = tbl[rpi_sa].reshape(n, n, heads).permute(2, 1, 0).contiguous()      # [heads][key][query]
-                blks.append(dict(
+                blks.append(dict(rel=tbl.t().contiguous(),                                 # [heads][(2ws-1)^2] compact table
                     n1=(w(q + "norm1.weight"), w(q + "norm1.bias")), qkv=lin(q + "attn.qkv"), proj=lin(q + "attn.proj"),
                     bias=bias, cab0=(w.conv(q + "conv_block.cab.0"), w(q + "conv_block.cab.0.bias")),
                     cab2=(w.conv(q + "conv_block.cab.2"), w(q + "conv_block.cab.2.bias")),
@@ -137,7 +143,8 @@ class HatHIP:
         att = torch.empty_like(x)
         s = blk["shift"]
         ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
-                        kwin=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, heads=self.heads, d=d, scale=d ** -0.5)
+                        kwin=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, heads=self.heads, d=d, scale=d ** -0.5,
+                        rel_table=blk["rel"] if _REL_BIAS else None)
         c1 = ops.conv2d(xn, *blk["cab0"], ksize=(3, 3), pad=(1, 1), act="gelu")
         c2 = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1))
         gate = ops.vec_mlp(ops.pool_mean(c2), *blk["ca1"], "relu", *blk["ca2"], "sigmoid", post=self.conv_scale)
@@ -212,7 +219,8 @@ def _dat_dpb_bias(sd: SD, p: str, hs: int, wsz: int, heads: int) -> T:
     cy, cx = cy.reshape(-1), cx.reshape(-1)
     idx = (cy[:, None] - cy[None, :] + hs - 1) * (2 * wsz - 1) + (cx[:, None] - cx[None, :] + wsz - 1)
     n = hs * wsz
-    return t[idx.reshape(-1)].reshape(n, n, heads).permute(2, 1, 0).contiguous()            # [heads][key][query]
+    # expanded [heads][key][query] for the f32 kernel, compact [heads][(2hs-1)*(2wsz-1)] for the LDS gather of the bf16 kernel
+    return t[idx.reshape(-1)].reshape(n, n, heads).permute(2, 1, 0).contiguous(), t.t().contiguous()
 
 
 def dat_should_shift(g: int, b: int) -> bool:
@@ -259,9 +267,10 @@ class DatHIP:
                     sgn=(w(q + "ffn.sg.norm.weight"), w(q + "ffn.sg.norm.bias")),
                     sgc=(pack_dw(w(q + "ffn.sg.conv.weight")), w(q + "ffn.sg.conv.bias")), fc2=lin(q + "ffn.fc2"))
                 if blk["spatial"]:
-                    blk["bias"] = [
-                        _dat_dpb_bias(sd, prefix + q + "attn.attns.0.pos", split[0], split[1], heads // 2).to(dev),
-                        _dat_dpb_bias(sd, prefix + q + "attn.attns.1.pos", split[1], split[0], heads // 2).to(dev)]
+                    pb = [_dat_dpb_bias(sd, prefix + q + "attn.attns.0.pos", split[0], split[1], heads // 2),
+                          _dat_dpb_bias(sd, prefix + q + "attn.attns.1.pos", split[1], split[0], heads // 2)]
+                    blk["bias"] = [pb[0][0].to(dev), pb[1][0].to(dev)]
+                    blk["rel"] = [pb[0][1].to(dev), pb[1][1].to(dev)]
                 else:
                     blk["temp"] = w(q + "attn.temperature").reshape(-1).contiguous()
                 blks.append(blk)
@@ -293,7 +302,8 @@ class DatHIP:
                 sh = (wh // 2, ww // 2) if blk["shifted"] else (0, 0)
                 ops.window_attn(qkv, att, blk["bias"][br], q_off=br * half, k_off=C + br * half, v_off=2 * C + br * half,
                                 o_off=br * half, H=H, W=W, Hp=Hp, Wp=Wp, win=(wh, ww), kwin=(wh, ww), shift=sh,
-                                use_mask=blk["shifted"], heads=hh, d=d, scale=d ** -0.5)
+                                use_mask=blk["shifted"], heads=hh, d=d, scale=d ** -0.5,
+                                rel_table=blk["rel"][br] if _REL_BIAS else None)
             ch_in, sp_in = conv_x, att
         else:
             wbd = ops.chan_attn_weights(qkv, 0, C, blk["temp"])

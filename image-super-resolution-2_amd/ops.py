@@ -250,7 +250,7 @@ def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] =
 
 def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int, o_off: int, H: int, W: int, Hp: int,
                 Wp: int, win: Tuple[int, int], kwin: Tuple[int, int], shift: Tuple[int, int], use_mask: bool, heads: int,
-                d: int, scale: float) -> T:
+                d: int, scale: float, rel_table: Optional[T] = None) -> T:
     qp, ldq, B, h_, w_, _ = _nhwc(qkv, "window_attn.qkv")
     op, ldo, *_ = _nhwc(out, "window_attn.out")
     if (h_, w_) != (H, W) or tuple(out.shape[:3]) != (B, H, W):
@@ -266,6 +266,11 @@ def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int,
                                        win[1], kwin[0], kwin[1], shift[0], shift[1], int(use_mask), heads, d, float(scale),
                                        _stream()))
     else:
+        relp = None
+        if rel_table is not None and tuple(kwin) == tuple(win) and win[1] & (win[1] - 1) == 0 and win[1] >= 8:
+            if tuple(rel_table.shape) != (heads, (2 * win[0] - 1) * (2 * win[1] - 1)) or not rel_table.is_contiguous():
+                raise _lib.FFError("window_attn: rel_table must be [heads, (2wh-1)*(2ww-1)]")
+            relp = rel_table.data_ptr()
         bq = getattr(biasT, "_ff_quad", None)
         if bq is None:                              # load-time relayout, cached on the table
             from . import prep as _prep
@@ -273,7 +278,7 @@ def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int,
             biasT._ff_quad = bq
         _lib.check(_L().ff_window_attn_bf16s(qp, ldq, q_off, k_off, v_off, op, ldo, o_off, bq.data_ptr(), B, H, W, Hp, Wp,
                                              win[0], win[1], kwin[0], kwin[1], shift[0], shift[1], int(use_mask), heads, d,
-                                             float(scale), 1 if _GEMM_MODE == "bf16" else 3, _stream()))
+                                             float(scale), 1 if _GEMM_MODE == "bf16" else 3, relp, _stream()))
     nwin = B * (Hp // win[0]) * (Wp // win[1])
     _note(4.0 * nwin * heads * 256 * nk * d, 4.0 * (4.0 * B * H * W * heads * d + heads * nk * 256))
     return out

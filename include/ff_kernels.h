@@ -73,10 +73,15 @@ int ff_window_attn(const float* qkv, int ldq, int q_off, int k_off, int v_off, f
  * (hi*hi + lo*hi + hi*lo for both QK^T and PV), 1 = plain bf16 operands.  Same arguments otherwise, except that the
  * bias table is quad-interleaved: biasT[head][key / 4][query][key % 4] (= the table of ff_window_attn reshaped
  * [heads][nk/4][4][256] and permuted (0,1,3,2); prep.quad_bias), so four consecutive keys of a query are one 16-byte load.
- * kh*kw % 4 == 0. */
+ * kh*kw % 4 == 0.
+ * rel_table (optional, may be NULL): the compact relative-position table [heads][(2wh-1)*(2ww-1)] with
+ *   bias[q][k] = rel_table[head][(qy - ky + wh - 1)*(2ww - 1) + (qx - kx + ww - 1)]     (hat_arch.py:882-899, dat_arch.py:300-318)
+ * gathered from LDS instead of streaming the expanded table (then biasT may be NULL); needs keys == query window and a
+ * power-of-two window width. */
 int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_off, int v_off, float* out, int ldo, int o_off,
                          const float* biasT, int B, int H, int W, int Hp, int Wp, int wh, int ww, int kh, int kw,
-                         int shift_h, int shift_w, int use_mask, int heads, int d, float scale, int nterms, void* stream);
+                         int shift_h, int shift_w, int use_mask, int heads, int d, float scale, int nterms, const float* rel_table,
+                         void* stream);
 
 /* Fused transformer feed-forward on tokens (csrc/token_mlp.hip): out = x + fc2(GELU(fc1(LayerNorm(x)))), bf16x3 MFMA.
  * Replaces hat_arch.py:307 (norm2 + Mlp.forward :88-94 + residual) in one launch; the hidden activation stays on chip.

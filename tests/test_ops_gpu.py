@@ -270,6 +270,12 @@ def test_window_attn_hat(dev, gemm_mode, H, W, shift):
     if shift:
         o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
     close(out, o, GEMM_TOL[gemm_mode], "window_attn")
+    if gemm_mode != "f32":          # same bias values gathered from the compact (2ws-1)^2 table in LDS: bit-identical
+        out2 = torch.zeros(1, H, W, C, device=dev)
+        ops.window_attn(qkv, out2, bias.transpose(1, 2).contiguous(), q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W,
+                        win=(ws, ws), kwin=(ws, ws), shift=(shift, shift), use_mask=shift > 0, heads=heads, d=d, scale=d ** -0.5,
+                        rel_table=table.t().contiguous())
+        assert torch.equal(out, out2), "relative-position gather differs from the expanded table"
 
 
 def test_window_attn_ocab(dev, gemm_mode):
@@ -308,10 +314,20 @@ def test_window_attn_dat_branches(dev, gemm_mode, H, W, shifted):
     for br in range(2):
         wh, ww = (8, 32) if br == 0 else (32, 8)
         sh, sw = wh // 2, ww // 2
-        bias = rnd(hh, 256, 256, dev=dev, seed=26 + br, scale=0.5)
+        rel = rnd(hh, (2 * wh - 1) * (2 * ww - 1), dev=dev, seed=26 + br, scale=0.5)          # DynamicPosBias output per offset
+        cy, cx = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")
+        cy, cx = cy.reshape(-1).to(dev), cx.reshape(-1).to(dev)
+        idx = (cy[:, None] - cy[None, :] + wh - 1) * (2 * ww - 1) + (cx[:, None] - cx[None, :] + ww - 1)   # dat_arch.py:300-318
+        bias = rel[:, idx]                                                                     # (heads, nq, nk)
         ops.window_attn(qkv, out, bias.transpose(1, 2).contiguous(), q_off=br * half, k_off=C + br * half,
                         v_off=2 * C + br * half, o_off=br * half, H=H, W=W, Hp=Hp, Wp=Wp, win=(wh, ww), kwin=(wh, ww),
                         shift=(sh, sw) if shifted else (0, 0), use_mask=shifted, heads=hh, d=d, scale=d ** -0.5)
+        if gemm_mode != "f32":
+            out2 = torch.zeros_like(out)
+            ops.window_attn(qkv, out2, bias.transpose(1, 2).contiguous(), q_off=br * half, k_off=C + br * half,
+                            v_off=2 * C + br * half, o_off=br * half, H=H, W=W, Hp=Hp, Wp=Wp, win=(wh, ww), kwin=(wh, ww),
+                            shift=(sh, sw) if shifted else (0, 0), use_mask=shifted, heads=hh, d=d, scale=d ** -0.5, rel_table=rel)
+            assert torch.equal(out[..., br * half:(br + 1) * half], out2[..., br * half:(br + 1) * half]), "rel gather != expanded"
         t = qkv5[..., br * half:(br + 1) * half]
         if shifted:
             t = torch.roll(t, shifts=(-sh, -sw), dims=(1, 2))
