@@ -8,6 +8,7 @@ step is a libff_hip.so kernel (ops.py), PyTorch only allocates.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
