@@ -200,3 +200,43 @@ extern "C" int ff_tile_normalize(float* acc, const float* wsum, int C, int H, in
   FF_LAUNCH_CHECK("ff_tile_normalize");
   return FF_OK;
 }
+
+// ---- image I/O conversions of the plugin (reference io.py:64-76), SURVEY 8(f) rank 3: only uint8 crosses PCIe ------------------
+// uint8 HWC [H][W][3] -> fp32 NCHW [1][3][H][W], value / 255 (IEEE division, as numpy's float32 array / 255.0)
+__global__ __launch_bounds__(256) void u8hwc_to_f32nchw_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, int H, int W) {
+  const long long total = (long long)3 * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i % ((long long)H * W);
+    const int c = (int)(i / ((long long)H * W));
+    out[i] = __fdiv_rn((float)in[pix * 3 + c], 255.0f);
+  }
+}
+
+// fp32 NCHW [1][3][H][W] -> uint8 HWC: clamp to [0,1], * 255, round half to even (numpy .round()), as io.py:71-76
+__global__ __launch_bounds__(256) void f32nchw_to_u8hwc_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, int H, int W) {
+  const long long total = (long long)3 * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i / 3;
+    const int c = (int)(i - pix * 3);
+    const float v = fminf(fmaxf(in[(long long)c * H * W + pix], 0.f), 1.f);
+    out[i] = (unsigned char)rintf(__fmul_rn(v, 255.0f));
+  }
+}
+
+extern "C" int ff_u8hwc_to_f32nchw(const unsigned char* in, float* out, int H, int W, void* stream) {
+  FF_CHECK_ARG(in && out && H > 0 && W > 0, "ff_u8hwc_to_f32nchw: bad args");
+  long long nb = ((long long)3 * H * W + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(u8hwc_to_f32nchw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, out, H, W);
+  FF_LAUNCH_CHECK("ff_u8hwc_to_f32nchw");
+  return FF_OK;
+}
+
+extern "C" int ff_f32nchw_to_u8hwc(const float* in, unsigned char* out, int H, int W, void* stream) {
+  FF_CHECK_ARG(in && out && H > 0 && W > 0, "ff_f32nchw_to_u8hwc: bad args");
+  long long nb = ((long long)3 * H * W + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(f32nchw_to_u8hwc_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, out, H, W);
+  FF_LAUNCH_CHECK("ff_f32nchw_to_u8hwc");
+  return FF_OK;
+}

@@ -476,6 +476,33 @@ def affine(x: T, scale: T, shift: T, act=None, out: Optional[T] = None) -> T:
     return out
 
 
+def u8_to_f32_image(img_u8: T) -> T:
+    """uint8 HWC [H,W,3] on the device -> fp32 [1,3,H,W] in [0,1] (reference io.py:64-68)."""
+    if not (isinstance(img_u8, torch.Tensor) and img_u8.is_cuda and img_u8.dtype == torch.uint8 and img_u8.dim() == 3
+            and img_u8.shape[2] == 3 and img_u8.is_contiguous()):
+        raise _lib.FFError("u8_to_f32_image: expected a contiguous CUDA(HIP) uint8 [H,W,3] tensor")
+    H, W, _ = img_u8.shape
+    out = torch.empty((1, 3, H, W), device=img_u8.device, dtype=torch.float32)
+    _lib.check(_L().ff_u8hwc_to_f32nchw(img_u8.data_ptr(), out.data_ptr(), H, W, _stream()))
+    return out
+
+
+def f32_to_u8_image(x: T) -> T:
+    """fp32 [1,3,H,W] (or [3,H,W]) -> uint8 HWC [H,W,3]: clamp, *255, round half to even (reference io.py:71-76)."""
+    _chk(x, "f32_to_u8_image.x")
+    if x.dim() == 4:
+        if x.shape[0] != 1:
+            raise _lib.FFError("f32_to_u8_image: batch must be 1")
+        x = x[0]
+    if x.dim() != 3 or x.shape[0] != 3:
+        raise _lib.FFError("f32_to_u8_image: expected [1,3,H,W] or [3,H,W]")
+    x = x.contiguous()
+    _, H, W = x.shape
+    out = torch.empty((H, W, 3), device=x.device, dtype=torch.uint8)
+    _lib.check(_L().ff_f32nchw_to_u8hwc(x.data_ptr(), out.data_ptr(), H, W, _stream()))
+    return out
+
+
 def nchw_to_nhwc(x: T, Hp: Optional[int] = None, Wp: Optional[int] = None, add: Optional[T] = None,
                  pad_mode: str = "zero", out: Optional[T] = None) -> T:
     _chk(x, "nchw_to_nhwc.x")

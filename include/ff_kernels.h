@@ -163,6 +163,12 @@ int ff_fma3(float* out, int ldo, const float* a, int lda, const float* b, int ld
 int ff_affine(float* out, int ldo, const float* in, int ldi, long long rows, int C, const float* scale,
               const float* shift, int act, void* stream);
 
+/* Image I/O conversions of the plugin on the device (reference io.py:64-68 _load_image, :71-76 _save_image), so only uint8
+ * crosses PCIe: in HWC uint8 [H][W][3] -> out fp32 [1][3][H][W] = v / 255 (IEEE division); and back: clamp to [0,1], * 255,
+ * round half to even, uint8 HWC. */
+int ff_u8hwc_to_f32nchw(const unsigned char* in, float* out, int H, int W, void* stream);
+int ff_f32nchw_to_u8hwc(const float* in, unsigned char* out, int H, int W, void* stream);
+
 /* NCHW image -> NHWC (+add[c]), padded to (Hp, Wp) with zeros (0) or reflection (1)
  * (expert_loader.py:63-96; nafnet_arch.py:220-225), and back (+add[c], crop, optional clamp to [0,1]). */
 int ff_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Hp, int Wp, int ldo,

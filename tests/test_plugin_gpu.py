@@ -154,3 +154,21 @@ def test_model_from_broadcast_state_dict(dev, hip_model, synth_sd):
     assert all(v.is_cuda for v in sd_dev.values())
     lr = torch.from_numpy(np.random.default_rng(3).random((1, 3, 40, 48), dtype=np.float32)).to(dev)
     assert torch.equal(FreqFusionHIP(sd_dev, dev)(lr), hip_model(lr))
+
+
+def test_image_conversions_bit_exact(dev):
+    """ff_u8hwc_to_f32nchw / ff_f32nchw_to_u8hwc against the reference's numpy formulas (io.py:64-76): bit-exact, including
+    values that sit exactly on a rounding tie after the multiply by 255 and values outside [0,1]."""
+    from isr2_amd import ops
+    rng = np.random.default_rng(9)
+    u8 = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    got = ops.u8_to_f32_image(torch.from_numpy(u8).to(dev)).cpu().numpy()
+    ref = (u8.astype(np.float32) / 255.0).transpose(2, 0, 1)[None]
+    assert got.dtype == np.float32 and np.array_equal(got, ref)
+    f = rng.random((1, 3, 41, 29), dtype=np.float32) * 1.4 - 0.2                 # some values outside [0,1]
+    ties = (np.arange(0, 255, dtype=np.float32) + 0.5) / 255.0                    # k + 0.5 after * 255 (up to rounding)
+    f.reshape(-1)[:ties.size] = ties
+    f.reshape(-1)[ties.size:2 * ties.size] = np.nextafter(ties, np.float32(1))
+    got = ops.f32_to_u8_image(torch.from_numpy(f).to(dev)).cpu().numpy()
+    ref = (np.clip(f[0], 0, 1).transpose(1, 2, 0) * 255.0).round().astype(np.uint8)
+    assert got.dtype == np.uint8 and np.array_equal(got, ref)
