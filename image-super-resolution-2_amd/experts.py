@@ -141,7 +141,7 @@ class HatHIP:
         d = C // self.heads
         xn = ops.layernorm(x, *blk["n1"])                          # also feeds the conv branch, so it is materialised
         qkv = ops.token_linear(xn, _tl(blk, "qkv")) if _fast() else ops.linear(xn, *blk["qkv"])
-        att = torch.empty_like(x)
+        att = ops.empty_like_rows(x)
         s = blk["shift"]
         ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
                         kwin=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, heads=self.heads, d=d, scale=d ** -0.5,
@@ -163,7 +163,7 @@ class HatHIP:
             qkv = ops.token_linear(x, _tl(blk, "qkv"), gamma=blk["n1"][0], beta=blk["n1"][1])      # LayerNorm fused
         else:
             qkv = ops.linear(ops.layernorm(x, *blk["n1"]), *blk["qkv"])
-        att = torch.empty_like(x)
+        att = ops.empty_like_rows(x)
         ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
                         kwin=(self.ows, self.ows), shift=(0, 0), use_mask=False, heads=self.heads, d=d, scale=d ** -0.5)
         x = ops.token_linear(att, _tl(blk, "proj"), res=x) if _fast() else ops.linear(att, *blk["proj"], res=x)
@@ -297,7 +297,7 @@ class DatHIP:
         if blk["spatial"]:
             m = max(self.split)
             Hp, Wp = _ceil_to(H, m), _ceil_to(W, m)
-            att = torch.empty_like(x)
+            att = ops.empty_like_rows(x)
             for br in range(2):
                 wh, ww = (self.split[0], self.split[1]) if br == 0 else (self.split[1], self.split[0])
                 sh = (wh // 2, ww // 2) if blk["shifted"] else (0, 0)

@@ -103,6 +103,23 @@ def set_halo(on: bool) -> None:
 _PAD_PITCH = _os.environ.get("FF_PAD_PITCH", "1") != "0"
 
 
+_PAD_ROWS = _os.environ.get("FF_PAD_ROWS", "1") != "0"
+
+
+def empty_rows(shape, device) -> T:
+    """fp32 activation buffer [..., C].  The row pitch is rounded up (FF_PAD_ROWS=0 disables) to a multiple of 32 floats when C is
+    not one already (180 -> 192, 60 -> 64, 720 -> 736): every 32-channel segment a GEMM epilogue stores is then a whole
+    128-byte line instead of straddling two.  Kernels take the pitch as their ld argument; the padding is never touched."""
+    C = int(shape[-1])
+    if _PAD_ROWS and C >= 48 and C % 32 != 0:
+        return torch.empty(tuple(shape[:-1]) + ((C + 31) // 32 * 32,), device=device, dtype=torch.float32)[..., :C]
+    return torch.empty(tuple(shape), device=device, dtype=torch.float32)
+
+
+def empty_like_rows(x: T) -> T:
+    return empty_rows(tuple(x.shape), x.device)
+
+
 def _split_weight(w: T, dynamic: bool, cin: int):
     """bf16 hi/lo planes [N][Kp] of a packed fp32 weight [N][taps*cin]; cached on the tensor object unless
     `dynamic`.  Per-tap padded (TAP) K layout when cin >= 32 and cin % 4 == 0, flat otherwise."""
@@ -181,7 +198,7 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
     Wo = (W + 2 * pad[1] - KW) // stride[1] + 1
     oshape = (B, Ho * 2, Wo * 2, Cout // 4) if shuffle == 2 else (B, Ho, Wo, Cout)
     if out is None:
-        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+        out = empty_rows(oshape, x.device)
     elif tuple(out.shape) != oshape:
         raise _lib.FFError(f"conv2d: out shape {tuple(out.shape)} != {oshape}")
     op, ldo, *_ = _nhwc(out, "conv2d.out")
@@ -226,7 +243,7 @@ def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] =
         raise _lib.FFError(f"linear: weight must be [N, {K}], got {tuple(w.shape)}")
     oshape = tuple(x.shape[:-1]) + (N,)
     if out is None:
-        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+        out = empty_rows(oshape, x.device)
     op, ldo, orows, oc = rows_view(out, "linear.out")
     if orows != rows or oc != N:
         raise _lib.FFError("linear: out shape mismatch")
@@ -289,8 +306,9 @@ def token_mlp(x: T, gamma: T, beta: T, pk: dict, eps: float = 1e-5) -> T:
     xp, ldx, rows, K = rows_view(x, "token_mlp.x")
     if K != pk["K"] or pk["N"] != K:
         raise _lib.FFError("token_mlp: shape mismatch")
-    out = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
-    _lib.check(_L().ff_token_mlp(xp, ldx, out.data_ptr(), K, rows, K, pk["ht"], pk["N"], gamma.data_ptr(), beta.data_ptr(),
+    out = empty_like_rows(x)
+    op_, ldo_, _, _ = rows_view(out, "token_mlp.out")
+    _lib.check(_L().ff_token_mlp(xp, ldx, op_, ldo_, rows, K, pk["ht"], pk["N"], gamma.data_ptr(), beta.data_ptr(),
                                  float(eps), pk["w"].data_ptr(), pk["b1"].data_ptr(), pk["b2"].data_ptr(), _stream()))
     _note(4.0 * rows * K * pk["ht"] * 32, 8.0 * rows * K)
     return out
@@ -305,7 +323,7 @@ def token_linear(x: T, pk: dict, *, gamma: Optional[T] = None, beta: Optional[T]
     N = pk["N"]
     # wide outputs (qkv, fc1) get a row pitch that is a multiple of 32 floats: every 32-column store segment of the kernel
     # is then one whole 128-byte line (no partial-line writes); consumers take the pitch as their ld argument
-    ldo = (N + 31) // 32 * 32 if (_PAD_PITCH and N > 192) else N
+    ldo = (N + 31) // 32 * 32 if ((_PAD_PITCH and N > 192) or (_PAD_ROWS and N >= 48)) else N
     out = torch.empty(tuple(x.shape[:-1]) + (ldo,), device=x.device, dtype=torch.float32)[..., :N]
     rp, ldr, r2p, ldr2 = None, 0, None, 0
     if res is not None:
@@ -353,7 +371,7 @@ def naf_ffn(y: T, pk: dict, ln_g: T, ln_b: T, out_scale: T, eps: float = 1e-6) -
 def layernorm(x: T, gamma: T, beta: T, eps: float = 1e-5, out: Optional[T] = None) -> T:
     xp, ldi, rows, C = rows_view(x, "layernorm.x")
     if out is None:
-        out = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
+        out = empty_like_rows(x)
     op, ldo, orows, oc = rows_view(out, "layernorm.out")
     if orows != rows or oc != C or gamma.numel() != C or beta.numel() != C:
         raise _lib.FFError("layernorm: shape mismatch")
@@ -397,7 +415,7 @@ def dwconv2d(x: T, w_tap: T, bias: Optional[T] = None, *, ksize=(3, 3), stride=(
     Ho = (H + 2 * pad[0] - KH) // stride[0] + 1
     Wo = (W + 2 * pad[1] - KW) // stride[1] + 1
     if out is None:
-        out = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.float32)
+        out = empty_rows((B, Ho, Wo, C), x.device)
     op, ldo, *_ = _nhwc(out, "dwconv2d.out")
     mp, ldm = None, 0
     if mul_in is not None:
@@ -420,7 +438,7 @@ def mix2(a: T, b: Optional[T] = None, *, ka: float = 1.0, kb: float = 1.0, ca: O
         if brows != rows or bc != C:
             raise _lib.FFError("mix2: a/b shape mismatch")
     if out is None:
-        out = torch.empty(tuple(a.shape), device=a.device, dtype=torch.float32)
+        out = empty_like_rows(a)
     op, ldo, orows, oc = rows_view(out, "mix2.out")
     if orows != rows or oc != C:
         raise _lib.FFError("mix2: out shape mismatch")
@@ -455,7 +473,7 @@ def fma3(a: Optional[T], b: T, c: T, alpha: float = 1.0, out: Optional[T] = None
         if arows != rows or ac != C:
             raise _lib.FFError("fma3: a shape mismatch")
     if out is None:
-        out = torch.empty(tuple(b.shape), device=b.device, dtype=torch.float32)
+        out = empty_like_rows(b)
     op, ldo, orows, oc = rows_view(out, "fma3.out")
     if orows != rows or oc != C:
         raise _lib.FFError("fma3: out shape mismatch")
@@ -467,7 +485,7 @@ def fma3(a: Optional[T], b: T, c: T, alpha: float = 1.0, out: Optional[T] = None
 def affine(x: T, scale: T, shift: T, act=None, out: Optional[T] = None) -> T:
     xp, ldi, rows, C = rows_view(x, "affine.x")
     if out is None:
-        out = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
+        out = empty_like_rows(x)
     op, ldo, orows, oc = rows_view(out, "affine.out")
     if orows != rows or oc != C or scale.numel() != C or shift.numel() != C:
         raise _lib.FFError("affine: shape mismatch")
@@ -510,7 +528,7 @@ def nchw_to_nhwc(x: T, Hp: Optional[int] = None, Wp: Optional[int] = None, add: 
     B, C, H, W = x.shape
     Hp, Wp = Hp or H, Wp or W
     if out is None:
-        out = torch.empty((B, Hp, Wp, C), device=x.device, dtype=torch.float32)
+        out = empty_rows((B, Hp, Wp, C), x.device)
     op, ldo, *_ = _nhwc(out, "nchw_to_nhwc.out")
     _lib.check(_L().ff_nchw_to_nhwc(x.data_ptr(), op, B, C, H, W, Hp, Wp, ldo, _ptr(add), 1 if pad_mode == "reflect" else 0,
                                     _stream()))
