@@ -92,18 +92,22 @@ __device__ __forceinline__ void ff_wave_rows_to_frags(const float* __restrict__ 
                                                       float* xs, int lane, float (&v)[4 * NPASS][8]) {
   const int l31 = lane & 31, hh = lane >> 5;
   const int rr = lane >> 4, cq = (lane & 15) * 4;
+  // every pass's loads are issued before the first one is consumed: one exposed HBM latency per wave instead of NPASS
+  f32x4 t[NPASS][8];
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
-    f32x4 t[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int r = 4 * j + rr, c = 64 * pass + cq;
       const bool ok = tok0 + r < M && c < K;
       const f32x4 u = *reinterpret_cast<const f32x4*>(x + (ok ? (tok0 + r) * ldx + c : 0));
-      t[j] = ok ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
+      t[pass][j] = ok ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+  }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(xs + (4 * j + rr) * FF_XS_ROW + cq) = t[j];
+  for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(xs + (4 * j + rr) * FF_XS_ROW + cq) = t[pass][j];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(xs + l31 * FF_XS_ROW + 16 * s4 + 8 * hh);
