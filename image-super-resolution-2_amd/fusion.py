@@ -193,6 +193,23 @@ class HierFusion:
                                  rs=float(sd[f"{p}.{name}_res.scale"].cpu()))
         self.rgb0, self.rgb2 = _conv_b(sd, p + ".to_rgb.0", dev), _conv_b(sd, p + ".to_rgb.2", dev)
         self.w12, self.w23 = float(sd[p + ".residual_weight_1_2"].cpu()), float(sd[p + ".residual_weight_2_3"].cpu())
+        # stage 2 / 3 read cat(features 64, experts 9) = 73 channels (hierarchical_fusion.py:160,176).  The concat buffers are
+        # given 76 channels (three that stay zero) and the weights three zero input columns per tap, so the convolution takes
+        # the 16-byte-aligned / LDS-resident path instead of the scalar gather (915 -> ~500 us at 1024x1024).
+        for name in ("stage2", "stage3"):
+            w, b = self.st[name]["c0"]
+            w76 = torch.zeros(w.shape[0], 9, 76, device=w.device)
+            w76[:, :, :73] = w.reshape(w.shape[0], 9, 73)
+            self.st[name]["c0"] = (w76.reshape(w.shape[0], 9 * 76).contiguous(), b)
+        self._cat = {}
+
+    def _cat_buf(self, h: int, w: int, dev, key: str) -> T:
+        """[1,h,w,76] concat buffer whose channels 73..75 are zero (allocated zeroed once per size; never written again)."""
+        buf = self._cat.get(key)                       # one buffer per role: a new image size replaces it
+        if buf is None or tuple(buf.shape) != (1, h, w, 76) or buf.device != torch.device(dev):
+            buf = torch.zeros((1, h, w, 76), device=dev, dtype=torch.float32)
+            self._cat[key] = buf
+        return buf
 
     def _stage(self, x: T, name: str) -> T:
         k = self.st[name]
@@ -208,14 +225,14 @@ class HierFusion:
         s1, s2 = (max(fh // 4, 1), max(fw // 4, 1)), (max(fh // 2, 1), max(fw // 2, 1))
         dev = experts9.device
         f1 = self._stage(ops.resize(experts9, s1), "stage1")                               # [1,h/4,w/4,64]
-        in2 = torch.empty((1, s2[0], s2[1], 73), device=dev, dtype=torch.float32)
+        in2 = self._cat_buf(s2[0], s2[1], dev, "in2")
         ops.resize(f1, s2, out=in2[..., :64])
-        ops.resize(experts9, s2, out=in2[..., 64:])
+        ops.resize(experts9, s2, out=in2[..., 64:73])
         f2 = self._stage(in2, "stage2")
         f2 = ops.mix2(f2, in2[..., :64], kb=self.w12)
-        in3 = torch.empty((1, fh, fw, 73), device=dev, dtype=torch.float32)
+        in3 = self._cat_buf(fh, fw, dev, "in3")
         ops.resize(f2, (fh, fw), out=in3[..., :64])
-        ops.mix2(experts9, out=in3[..., 64:])
+        ops.mix2(experts9, out=in3[..., 64:73])
         f3 = self._stage(in3, "stage3")                                                    # [1,fh,fw,32]
         f3 = ops.mix2(f3, in3[..., :32], kb=self.w23)
         o = ops.conv2d(f3, *self.rgb0, ksize=(3, 3), pad=(1, 1), act="gelu")
