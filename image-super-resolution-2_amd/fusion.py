@@ -349,20 +349,30 @@ class FusionHIP:
         self.res_scale = float(sd["residual_scale"].cpu())
         self.edge = EdgeRefine(sd, dev)
 
-    def forward(self, lr: T, experts: Dict[str, T], taps: Optional[dict] = None) -> T:
-        """lr NCHW [1,3,h,w]; experts: dict of NCHW [1,3,4h,4w] -> SR NCHW [1,3,4h,4w]."""
+    def pre(self, lr: T) -> dict:
+        """Everything that depends on the LR input only (frequency bands, cross-band attention, band fusion -> guidance,
+        dynamic-selection gates, the bilinear LR skip): independent of the experts, so model.py runs it beside them."""
         _, _, h, w = lr.shape
-        dev = lr.device
         raw = self.bands(lr)
         xb = self.xband(raw)
         b3 = self.bfuse(xb)
         guide = ops.freq_guidance(b3)
+        lr_nhwc = ops.nchw_to_nhwc(lr)
+        gates, dif = self.dyn(lr_nhwc)
+        up = ops.resize(lr_nhwc, (4 * h, 4 * w), mul=self.res_scale)
+        return dict(raw=raw, xb=xb, b3=b3, guide=guide, lr_nhwc=lr_nhwc, gates=gates, dif=dif, up=up)
+
+    def forward(self, lr: T, experts: Dict[str, T], taps: Optional[dict] = None, pre: Optional[dict] = None) -> T:
+        """lr NCHW [1,3,h,w]; experts: dict of NCHW [1,3,4h,4w] -> SR NCHW [1,3,4h,4w]."""
+        _, _, h, w = lr.shape
+        dev = lr.device
+        if pre is None:
+            pre = self.pre(lr)
+        raw, xb, b3, guide, gates, dif = pre["raw"], pre["xb"], pre["b3"], pre["guide"], pre["gates"], pre["dif"]
         e9 = torch.empty((1, 4 * h, 4 * w, 9), device=dev, dtype=torch.float32)
         for i, k in enumerate(("hat", "dat", "nafnet")):
             ops.nchw_to_nhwc(experts[k], out=e9[..., 3 * i:3 * i + 3])
         hier = self.hier(e9)
-        lr_nhwc = ops.nchw_to_nhwc(lr)
-        gates, dif = self.dyn(lr_nhwc)
         fused = ops.fuse_blend(e9, hier, guide, gates, dif)
         if taps is not None:
             for i in range(9):
@@ -375,8 +385,7 @@ class FusionHIP:
         r = ops.conv2d(r, *self.refine[1], ksize=(3, 3), pad=(1, 1), act="gelu")
         r = ops.conv2d(r, *self.refine[2], ksize=(3, 3), pad=(1, 1), act="gelu")
         f = ops.conv2d(r, *self.refine[3], ksize=(3, 3), pad=(1, 1), res=fused, alpha=0.1)
-        up = ops.resize(lr_nhwc, (4 * h, 4 * w), mul=self.res_scale)
-        f = ops.mix2(f, up, clamp01=True)
+        f = ops.mix2(f, pre["up"], clamp01=True)
         if taps is not None:
             taps["fusion.pre_edge"] = f
         out = self.edge(f)

@@ -36,28 +36,37 @@ class FreqFusionHIP:
             self.nafnet = NafnetHIP(state_dict, dev)
             self.fusion = FusionHIP(state_dict, dev)
 
-    def experts(self, lr: T, taps: Optional[dict] = None) -> Dict[str, T]:
+    def experts(self, lr: T, taps: Optional[dict] = None, with_pre: bool = False):
         """ExpertEnsemble.forward_all (expert_loader.py:768-777).  The three experts are independent until the fusion
         stack, so each runs on its own HIP stream (fork/join on the caller's stream; the whole fan-out is captured
-        into the HIP graph): latency-bound kernels of one expert overlap with bandwidth-bound kernels of another."""
+        into the HIP graph): latency-bound kernels of one expert overlap with bandwidth-bound kernels of another.
+        with_pre: also run the LR-only part of the fusion stack (FusionHIP.pre) behind the shortest expert's stream."""
         if not self.multi_stream or taps is not None:
-            return {"hat": self.hat.forward(lr, taps), "dat": self.dat.forward(lr, taps), "nafnet": self.nafnet.forward(lr, taps)}
+            ex = {"hat": self.hat.forward(lr, taps), "dat": self.dat.forward(lr, taps), "nafnet": self.nafnet.forward(lr, taps)}
+            return (ex, None) if with_pre else ex
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
         s1, s2 = self._side
         s1.wait_stream(main)
         s2.wait_stream(main)
+        pre = None
         with torch.cuda.stream(s1):
             dat = self.dat.forward(lr)
         with torch.cuda.stream(s2):
             naf = self.nafnet.forward(lr)
+            if with_pre:
+                pre = self.fusion.pre(lr)
         hat = self.hat.forward(lr)
         main.wait_stream(s1)
         main.wait_stream(s2)
         dat.record_stream(main)
         naf.record_stream(main)
-        return {"hat": hat, "dat": dat, "nafnet": naf}
+        if pre is not None:
+            for t in pre.values():
+                t.record_stream(main)
+        ex = {"hat": hat, "dat": dat, "nafnet": naf}
+        return (ex, pre) if with_pre else ex
 
     @torch.no_grad()
     def forward(self, lr: T, taps: Optional[dict] = None) -> T:
@@ -65,9 +74,9 @@ class FreqFusionHIP:
             raise _lib.FFError(f"expected lr of shape [1,3,h,w], got {tuple(lr.shape)}")
         lr = lr.to(self.dev, torch.float32).contiguous()
         with torch.cuda.device(self.dev):
-            ex = self.experts(lr, taps)
+            ex, pre = self.experts(lr, taps, with_pre=True)
             if taps is not None:
                 taps.update({f"expert.{k}": v for k, v in ex.items()})
-            return self.fusion.forward(lr, ex, taps)
+            return self.fusion.forward(lr, ex, taps, pre=pre)
 
     __call__ = forward
