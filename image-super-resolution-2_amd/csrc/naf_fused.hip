@@ -11,39 +11,62 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // --------------------------------------------------------------------------------------------- dwconv + gate + pool sums
+// A thread owns 4 channels (of each gate half) of a 4-row output strip at one column: a 6 x 3 input window and the 9 tap
+// weights per half live in registers, so an output costs 9 float4 input loads (18 with one pixel per thread) and the
+// weights are fetched once per strip.  The two halves are evaluated one after the other to reuse the window registers.
 __global__ __launch_bounds__(256) void dwconv3_gate_pool_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo,
                                                                 int H, int W, int C, const float* __restrict__ w, const float* __restrict__ bias,
                                                                 float* __restrict__ part) {
   extern __shared__ float4 red[];                      // [ppb][C/4]
-  const int cv = C >> 2, ppb = 256 / cv;               // float4 channel groups, pixels per block iteration
+  const int cv = C >> 2, ppb = 256 / cv;               // float4 channel groups, (column, strip) items per block iteration
   const int cg = threadIdx.x % cv, ps = threadIdx.x / cv;
-  const long long P = (long long)H * W;
-  float4 acc_sum = {0.f, 0.f, 0.f, 0.f};
+  const int nstrip = (H + 3) >> 2;
+  const long long items = (long long)nstrip * W;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc_sum = z4;
   if (ps < ppb) {
     const int c = 4 * cg;
-    const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + c), bb = *reinterpret_cast<const f32x4*>(bias + C + c);
-    for (long long p = (long long)blockIdx.x * ppb + ps; p < P; p += (long long)gridDim.x * ppb) {
-      const int x = (int)(p % W), y = (int)(p / W);
-      f32x4 a = ba, b = bb;
+    for (long long it = (long long)blockIdx.x * ppb + ps; it < items; it += (long long)gridDim.x * ppb) {
+      const int x = (int)(it % W), y0 = (int)(it / W) * 4;
+      f32x4 ga[4];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = y + ky - 1;
-        if ((unsigned)iy >= (unsigned)H) continue;
+      for (int half = 0; half < 2; ++half) {
+        const int ch = c + half * C;
+        f32x4 wt[9];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ix = x + kx - 1;
-          if ((unsigned)ix >= (unsigned)W) continue;
-          const float* src = in + ((long long)iy * W + ix) * ldi + c;
-          const float* wt = w + (ky * 3 + kx) * 2 * C + c;
-          a += *reinterpret_cast<const f32x4*>(src) * *reinterpret_cast<const f32x4*>(wt);
-          b += *reinterpret_cast<const f32x4*>(src + C) * *reinterpret_cast<const f32x4*>(wt + C);
+        for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const f32x4*>(w + k * 2 * C + ch);
+        const f32x4 bs = *reinterpret_cast<const f32x4*>(bias + ch);
+        f32x4 win[6][3];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const int iy = y0 - 1 + r;
+          const bool oky = (unsigned)iy < (unsigned)H;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int ix = x - 1 + k;
+            const bool ok = oky && (unsigned)ix < (unsigned)W;
+            const f32x4 u = *reinterpret_cast<const f32x4*>(in + (ok ? ((long long)iy * W + ix) * ldi + ch : 0));
+            win[r][k] = ok ? u : z4;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f32x4 a = bs;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) a += win[r + ky][kx] * wt[ky * 3 + kx];
+          ga[r] = half == 0 ? a : ga[r] * a;
         }
       }
-      const f32x4 g = a * b;
-      *reinterpret_cast<f32x4*>(out + p * ldo + c) = g;
-      acc_sum.x += g[0]; acc_sum.y += g[1]; acc_sum.z += g[2]; acc_sum.w += g[3];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (y0 + r < H) {
+          *reinterpret_cast<f32x4*>(out + ((long long)(y0 + r) * W + x) * ldo + c) = ga[r];
+          acc_sum += ga[r];
+        }
     }
-    red[ps * cv + cg] = acc_sum;
+    red[ps * cv + cg] = (float4){acc_sum[0], acc_sum[1], acc_sum[2], acc_sum[3]};
   }
   __syncthreads();
   if (ps == 0) {
@@ -88,7 +111,7 @@ extern "C" int ff_dwconv3_gate_pool(const float* in, int ldi, float* out, int ld
   FF_CHECK_ARG((((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)w_tapmajor) & 15) == 0 && (((uintptr_t)bias) & 15) == 0 && (((uintptr_t)work) & 15) == 0, "ff_dwconv3_gate_pool: 16-byte alignment required");
   const int cv = C / 4, ppb = 256 / cv;
   const long long P = (long long)H * W;
-  long long nb = (P + ppb - 1) / ppb;
+  long long nb = ((long long)((H + 3) / 4) * W + ppb - 1) / ppb;      // (column, 4-row strip) items
   if (nb > 1024) nb = 1024;      // 4 workgroups per CU: enough to stream at HBM rate, few enough partials to reduce
   FF_CHECK_ARG(work_floats >= nb * C, "ff_dwconv3_gate_pool: workspace too small");
   hipStream_t st = (hipStream_t)stream;
