@@ -22,6 +22,7 @@ struct TokenLinParams {
   const __bf16* w;                         // [NT][2 planes][32][192], rows >= N zero
   const float* bias;                       // [NT*32] zero padded (or NULL)
   const float* res; const float* res2; const float* rs2;
+  float* xn; int ldxn;                     // optional side output: the LayerNorm'ed rows (NULL: not written)
   long long M;
   int ldx, ldo, ldr, ldr2, K, N, NT, act;
   float eps;
@@ -107,6 +108,15 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
         const __bf16 h = (__bf16)f;
         xh[st][j] = h;
         xl[st][j] = (__bf16)(f - (float)h);
+        v[st][j] = f;
+      }
+      // side output of the normalised rows (HAT feeds them to the CAB convolution, hat_arch.py:272-274): the separate
+      // LayerNorm pass (read 47 MB, write 47 MB) becomes 47 MB of extra stores here.  A lane holds 8 consecutive channels
+      // of its row: two float4 stores; the 12 steps of a wave complete whole lines in L2 before they are evicted.
+      if (p.xn && tvalid) {
+        float* xr = p.xn + tok * p.ldxn + k0;
+        if (k0 < p.K) *reinterpret_cast<f32x4*>(xr) = (f32x4){v[st][0], v[st][1], v[st][2], v[st][3]};
+        if (k0 + 4 < p.K) *reinterpret_cast<f32x4*>(xr + 4) = (f32x4){v[st][4], v[st][5], v[st][6], v[st][7]};
       }
     }
   }
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
 extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, int K, int kpad, int N, int n_tiles,
                                const float* gamma, const float* beta, float eps, const void* w_tiles,
                                const float* bias_padded, int act, const float* res, int ldr, const float* res2, int ldr2,
-                               const float* res2_scale, void* stream) {
+                               const float* res2_scale, float* xn_out, int ldxn, void* stream) {
   FF_CHECK_ARG(x && out && w_tiles, "ff_token_linear: null pointer");
   FF_CHECK_ARG(M > 0 && K > 0 && K <= 192 && K % 4 == 0 && N > 0 && n_tiles * 32 >= N, "ff_token_linear: needs K <= 192 (K %% 4 == 0), n_tiles*32 >= N");
   FF_CHECK_ARG(kpad == 64 || kpad == 128 || kpad == 192, "ff_token_linear: kpad must be 64, 128 or 192");
@@ -240,9 +250,10 @@ extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, lon
   FF_CHECK_ARG((((uintptr_t)w_tiles) & 15) == 0 && (!gamma || ((((uintptr_t)gamma) & 15) == 0 && (((uintptr_t)beta) & 15) == 0)), "ff_token_linear: weights / gamma / beta must be 16-byte aligned");
   FF_CHECK_ARG(!res || ldr >= N, "ff_token_linear: ldr too small");
   FF_CHECK_ARG(!res2 || (ldr2 >= N && res2_scale), "ff_token_linear: res2 needs ldr2 >= N and a scale vector");
+  FF_CHECK_ARG(!xn_out || (gamma && ldxn >= K && ldxn % 4 == 0 && (((uintptr_t)xn_out) & 15) == 0), "ff_token_linear: xn_out needs LayerNorm parameters and 16-byte aligned rows");
   TokenLinParams p;
   p.x = x; p.out = out; p.gamma = gamma; p.beta = beta; p.w = (const __bf16*)w_tiles; p.bias = bias_padded;
-  p.res = res; p.res2 = res2; p.rs2 = res2_scale; p.M = M; p.ldx = ldx; p.ldo = ldo; p.ldr = ldr; p.ldr2 = ldr2;
+  p.res = res; p.res2 = res2; p.rs2 = res2_scale; p.xn = xn_out; p.ldxn = ldxn; p.M = M; p.ldx = ldx; p.ldo = ldo; p.ldr = ldr; p.ldr2 = ldr2;
   p.K = K; p.N = N; p.NT = n_tiles; p.act = act; p.eps = eps;
   const bool vec4 = (N % 4 == 0) && (ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && (!res || (ldr % 4 == 0 && (((uintptr_t)res) & 15) == 0)) &&
            (!res2 || (ldr2 % 4 == 0 && (((uintptr_t)res2) & 15) == 0 && (((uintptr_t)res2_scale) & 15) == 0));

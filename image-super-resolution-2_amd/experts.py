@@ -139,8 +139,11 @@ class HatHIP:
     def hab(self, x: T, blk: dict) -> T:
         _, H, W, C = x.shape
         d = C // self.heads
-        xn = ops.layernorm(x, *blk["n1"])                          # also feeds the conv branch, so it is materialised
-        qkv = ops.token_linear(xn, _tl(blk, "qkv")) if _fast() else ops.linear(xn, *blk["qkv"])
+        if _fast():                                                # LayerNorm inside the qkv launch; xn (conv branch) is its side output
+            qkv, xn = ops.token_linear(x, _tl(blk, "qkv"), gamma=blk["n1"][0], beta=blk["n1"][1], want_xn=True)
+        else:
+            xn = ops.layernorm(x, *blk["n1"])
+            qkv = ops.linear(xn, *blk["qkv"])
         att = ops.empty_like_rows(x)
         s = blk["shift"]
         ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),

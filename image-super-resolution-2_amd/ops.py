@@ -315,8 +315,9 @@ def token_mlp(x: T, gamma: T, beta: T, pk: dict, eps: float = 1e-5) -> T:
 
 
 def token_linear(x: T, pk: dict, *, gamma: Optional[T] = None, beta: Optional[T] = None, eps: float = 1e-5, act=None,
-                 res: Optional[T] = None, res2: Optional[T] = None, res2_scale: Optional[T] = None) -> T:
-    """res + res2*scale + act(LayerNorm?(x) @ W^T + b) for K <= 192 in one launch (bf16x3); pk from prep.pack_token_linear."""
+                 res: Optional[T] = None, res2: Optional[T] = None, res2_scale: Optional[T] = None, want_xn: bool = False):
+    """res + res2*scale + act(LayerNorm?(x) @ W^T + b) for K <= 192 in one launch (bf16x3); pk from prep.pack_token_linear.
+    want_xn: also return LayerNorm(x) (written by the same launch) -> (out, xn)."""
     xp, ldx, rows, K = rows_view(x, "token_linear.x")
     if K != pk["K"]:
         raise _lib.FFError("token_linear: K mismatch")
@@ -334,10 +335,17 @@ def token_linear(x: T, pk: dict, *, gamma: Optional[T] = None, beta: Optional[T]
         r2p, ldr2, rr, rc = rows_view(res2, "token_linear.res2")
         if rr != rows or rc != N or res2_scale is None or res2_scale.numel() != N:
             raise _lib.FFError("token_linear: res2 shape mismatch")
+    xn, xnp, ldxn = None, None, 0
+    if want_xn:
+        if gamma is None:
+            raise _lib.FFError("token_linear: want_xn needs LayerNorm parameters")
+        xn = empty_like_rows(x)
+        xnp, ldxn, _, _ = rows_view(xn, "token_linear.xn")
     _lib.check(_L().ff_token_linear(xp, ldx, out.data_ptr(), ldo, rows, K, pk["kpad"], N, pk["nt"], _ptr(gamma), _ptr(beta), float(eps),
-                                    pk["w"].data_ptr(), _ptr(pk["b"]), ACT[act], rp, ldr, r2p, ldr2, _ptr(res2_scale), _stream()))
-    _note(2.0 * rows * N * K, 4.0 * (rows * K + rows * N * (1 + (res is not None) + (res2 is not None))))
-    return out
+                                    pk["w"].data_ptr(), _ptr(pk["b"]), ACT[act], rp, ldr, r2p, ldr2, _ptr(res2_scale), xnp, ldxn,
+                                    _stream()))
+    _note(2.0 * rows * N * K, 4.0 * (rows * K * (2 if want_xn else 1) + rows * N * (1 + (res is not None) + (res2 is not None))))
+    return (out, xn) if want_xn else out
 
 
 def dwconv3_gate_pool(t: T, w_tap: T, bias: T):

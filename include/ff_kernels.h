@@ -111,11 +111,12 @@ int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const f
  * +residuals): hat_arch.py:272+172 (OCAB :397+400), :194+306; dat_arch.py:734+501, :559, :735+163.
  * kpad = K rounded up to 64 / 128 / 192.  w_tiles: bf16 [n_tiles][2][32][kpad] (hi, lo planes; rows >= N and cols >= K
  * zero) from prep.pack_token_linear;
- * bias zero padded to n_tiles*32 (or NULL). */
+ * bias zero padded to n_tiles*32 (or NULL).  xn_out (optional, needs gamma): the LayerNorm'ed rows are also written there
+ * (row pitch ldxn), which saves the separate ff_layernorm pass when another consumer needs them (HAT's CAB branch). */
 int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, int K, int kpad, int N, int n_tiles,
                     const float* gamma, const float* beta, float eps, const void* w_tiles, const float* bias_padded,
                     int act, const float* res, int ldr, const float* res2, int ldr2, const float* res2_scale,
-                    void* stream);
+                    float* xn_out, int ldxn, void* stream);
 
 /* NAFNet block fusions (csrc/naf_fused.hip).
  * ff_dwconv3_gate_pool: out[p][c] = dw3x3(in)[p][c] * dw3x3(in)[p][C + c] (conv2 + SimpleGate, nafnet_arch.py:78-81,51-52)

@@ -182,6 +182,11 @@ def test_token_linear(dev, M, N, ln, act, nres):
     out = ops.token_linear(x, pack_token_linear(w, bias), gamma=g if ln else None, beta=b if ln else None, act=act,
                            res=res if nres >= 1 else None, res2=res2 if nres == 2 else None, res2_scale=rs2 if nres == 2 else None)
     close(out, ref, 6e-5, "token_linear")
+    if ln:                               # LayerNorm'ed rows as a side output of the same launch
+        out2, xn = ops.token_linear(x, pack_token_linear(w, bias), gamma=g, beta=b, act=act, res=res if nres >= 1 else None,
+                                    res2=res2 if nres == 2 else None, res2_scale=rs2 if nres == 2 else None, want_xn=True)
+        assert torch.equal(out, out2)
+        close(xn, xin, 1e-5, "token_linear xn side output")
 
 
 @pytest.mark.parametrize("C,H,W", [(64, 40, 56), (128, 33, 20), (512, 16, 16), (1024, 8, 8)])
