@@ -230,3 +230,83 @@ extern "C" int ff_vec_mlp(const float* in, int B, int Cin, const float* W1, cons
   FF_LAUNCH_CHECK("ff_vec_mlp");
   return FF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Per-pixel two-layer MLP with a tiny hidden width and ONE output:  out[p] = act2( w2 . act1( W1 x[p] + b1 ) + b2 )
+// (DAT AdaptiveInteraction spatial gate, dat_arch.py:585-590: conv1x1 180->11 (+BN folded) -> GELU -> conv1x1 11->1 -> sigmoid).
+// As two GEMM launches this reads the 47 MB token tensor for 2 GFLOP and then runs a latency-bound 11->1 layer; here 16
+// lanes own one pixel (three float4 of its channels each, 256-byte coalesced loads), a lane keeps 4 pixels in registers so
+// every W1 row read from LDS is used four times, partial dot products are reduced across the 16 lanes, fp32 throughout.
+#define PM_MAXH 16
+// sum over the 16 lanes of a DPP row, result in every lane: two quad permutes, then the half-row and row mirrors (all lanes of
+// a quad / half already hold the same partial sum when they are mirrored).  DPP modifiers run at VALU rate; __shfl_xor would be
+// an LDS ds_bpermute per step.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+__global__ __launch_bounds__(256) void pixel_mlp_kernel(const float* __restrict__ in, int ldi, long long P, int C, int Hd,
+                                                        const float* __restrict__ W1, const float* __restrict__ b1, int act1,
+                                                        const float* __restrict__ w2, float b2, int act2, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float W1s[PM_MAXH * 192];
+  for (int i = threadIdx.x; i < PM_MAXH * 192; i += 256) {
+    const int j = i / 192, c = i - j * 192;
+    W1s[i] = (j < Hd && c < C) ? W1[j * C + c] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int g = lane >> 4, j16 = lane & 15;
+  const long long nwave = (long long)gridDim.x * 4;
+  for (long long base = ((long long)blockIdx.x * 4 + wid) * 16; base < P; base += nwave * 16) {
+    f32x4 x[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long pp = base + g + 4 * i;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = 4 * (j16 + 16 * k);
+        const bool ok = pp < P && c < C;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(in + (ok ? pp * ldi + c : 0));
+        x[i][k] = ok ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    float o[4] = {b2, b2, b2, b2};
+#pragma unroll 1
+    for (int j = 0; j < Hd; ++j) {
+      f32x4 wv[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wv[k] = *reinterpret_cast<const f32x4*>(W1s + j * 192 + 4 * (j16 + 16 * k));
+      const float bj = b1 ? b1[j] : 0.f, wj = w2[j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 a = x[i][0] * wv[0];
+        a += x[i][1] * wv[1];
+        a += x[i][2] * wv[2];
+        const float s = row16_sum((a[0] + a[1]) + (a[2] + a[3]));
+        o[i] = __builtin_fmaf(wj, ff_act_fast(s + bj, act1), o[i]);   // A&S erf GELU (|err| <= 1.5e-7), as in the MFMA epilogues
+      }
+    }
+    if (j16 == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long pp = base + g + 4 * i;
+        if (pp < P) out[pp] = ff_act(o[i], act2);
+      }
+    }
+  }
+}
+
+extern "C" int ff_pixel_mlp(const float* in, int ldi, long long P, int C, int hidden, const float* W1, const float* b1, int act1,
+                            const float* w2, float b2, int act2, float* out, void* stream) {
+  FF_CHECK_ARG(in && W1 && w2 && out, "ff_pixel_mlp: null pointer");
+  FF_CHECK_ARG(P > 0 && C > 0 && C <= 192 && C % 4 == 0 && ldi >= C && ldi % 4 == 0 && (((uintptr_t)in) & 15) == 0, "ff_pixel_mlp: needs C <= 192, C %% 4 == 0, 16-byte aligned rows");
+  FF_CHECK_ARG(hidden > 0 && hidden <= PM_MAXH, "ff_pixel_mlp: hidden width must be 1..16");
+  long long nb = (P + 63) / 64;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(pixel_mlp_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, ldi, P, C, hidden, W1, b1, act1, w2, b2, act2, out);
+  FF_LAUNCH_CHECK("ff_pixel_mlp");
+  return FF_OK;
+}

@@ -277,6 +277,7 @@ class DatHIP:
                     blk["rel"] = [pb[0][1].to(dev), pb[1][1].to(dev)]
                 else:
                     blk["temp"] = w(q + "attn.temperature").reshape(-1).contiguous()
+                blk["si3b"] = float(blk["si3"][1].reshape(-1)[0].cpu())                    # scalar bias of the 11 -> 1 layer
                 blks.append(blk)
             self.blocks.append(blks)
             self.gconv.append((w.conv(f"layers.{g}.conv"), w(f"layers.{g}.conv.bias")))
@@ -314,7 +315,10 @@ class DatHIP:
             att = ops.linear(v, wbd, dynamic_w=True)
             ch_in, sp_in = att, conv_x
         cm = ops.vec_mlp(ops.pool_mean(ch_in), *blk["ci1"], "gelu", *blk["ci4"], "sigmoid")              # [1,C]
-        sm = ops.linear(ops.linear(sp_in, *blk["si0"], act="gelu"), *blk["si3"], act="sigmoid")          # [1,H,W,1]
+        if _fast():                                                # 180 -> 11 -> 1 per pixel in one pass (fp32)
+            sm = ops.pixel_mlp(sp_in, blk["si0"][0], blk["si0"][1], "gelu", blk["si3"][0], blk["si3b"], "sigmoid")
+        else:
+            sm = ops.linear(ops.linear(sp_in, *blk["si0"], act="gelu"), *blk["si3"], act="sigmoid")      # [1,H,W,1]
         if blk["spatial"]:
             fused = ops.mix2(att, conv_x, ca=cm, pb=sm)
         else:

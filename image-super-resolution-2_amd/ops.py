@@ -413,6 +413,19 @@ def vec_mlp(v: T, W1: T, b1: Optional[T], act1, W2: Optional[T] = None, b2: Opti
     return out
 
 
+def pixel_mlp(x: T, W1: T, b1: Optional[T], act1, w2: T, b2: float, act2) -> T:
+    """[..., C] rows -> [..., 1]: act2(w2 . act1(W1 x + b1) + b2) per row, hidden width <= 16 (fp32, one launch)."""
+    xp, ldi, rows, C = rows_view(x, "pixel_mlp.x")
+    Hd = W1.shape[0]
+    if tuple(W1.shape) != (Hd, C) or w2.numel() != Hd or not W1.is_contiguous():
+        raise _lib.FFError("pixel_mlp: weight shape mismatch")
+    out = torch.empty(tuple(x.shape[:-1]) + (1,), device=x.device, dtype=torch.float32)
+    _lib.check(_L().ff_pixel_mlp(xp, ldi, rows, C, Hd, W1.data_ptr(), _ptr(b1), ACT[act1], w2.reshape(-1).data_ptr(), float(b2), ACT[act2],
+                                 out.data_ptr(), _stream()))
+    _note(2.0 * rows * C * Hd, 4.0 * rows * (C + 1))
+    return out
+
+
 def dwconv2d(x: T, w_tap: T, bias: Optional[T] = None, *, ksize=(3, 3), stride=(1, 1), pad=(1, 1),
              post_scale: Optional[T] = None, post_shift: Optional[T] = None, act=None, out: Optional[T] = None,
              mul_in: Optional[T] = None) -> T:
@@ -688,7 +701,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "linear", "token_mlp", "token_linear", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
+for _n in ("conv2d", "linear", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

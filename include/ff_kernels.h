@@ -164,6 +164,13 @@ int ff_fma3(float* out, int ldo, const float* a, int lda, const float* b, int ld
 int ff_affine(float* out, int ldo, const float* in, int ldi, long long rows, int C, const float* scale,
               const float* shift, int act, void* stream);
 
+/* Per-pixel two-layer MLP with a small hidden width and one output channel, fp32 (csrc/norm_pool.hip):
+ *   out[p] = act2( w2 . act1( W1 x[p] + b1 ) + b2 ),   W1 [hidden][C] (hidden <= 16, C <= 192, C % 4 == 0), w2 [hidden].
+ * Replaces the spatial-interaction branch of DAT's AdaptiveInteraction (dat_arch.py:585-590: conv1x1 + BN (folded) + GELU +
+ * conv1x1 + sigmoid) in one pass over the token tensor. */
+int ff_pixel_mlp(const float* in, int ldi, long long P, int C, int hidden, const float* W1, const float* b1, int act1,
+                 const float* w2, float b2, int act2, float* out, void* stream);
+
 /* Image I/O conversions of the plugin on the device (reference io.py:64-68 _load_image, :71-76 _save_image), so only uint8
  * crosses PCIe: in HWC uint8 [H][W][3] -> out fp32 [1][3][H][W] = v / 255 (IEEE division); and back: clamp to [0,1], * 255,
  * round half to even, uint8 HWC. */

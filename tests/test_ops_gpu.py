@@ -345,6 +345,18 @@ def test_window_attn_dat_branches(dev, gemm_mode, H, W, shifted):
         close(out[..., br * half:(br + 1) * half], o[:, :H, :W], GEMM_TOL[gemm_mode], f"dat branch {br}")
 
 
+@pytest.mark.parametrize("P,C,Hd", [(65536, 180, 11), (1000, 64, 16), (77, 192, 3)])
+def test_pixel_mlp(dev, P, C, Hd):
+    """DAT spatial-interaction gate (dat_arch.py:585-590) as one per-pixel kernel against the PyTorch chain."""
+    from isr2_amd import ops
+    wide = rnd(P, C + 12, dev=dev, seed=150)
+    x = wide[:, 4:4 + C]
+    W1, b1 = rnd(Hd, C, dev=dev, seed=151, scale=1.0 / math.sqrt(C)), rnd(Hd, dev=dev, seed=152, scale=0.1)
+    w2, b2 = rnd(1, Hd, dev=dev, seed=153, scale=0.5), 0.37
+    ref = torch.sigmoid(F.linear(F.gelu(F.linear(x, W1, b1)), w2) + b2)
+    close(ops.pixel_mlp(x, W1, b1, "gelu", w2, b2, "sigmoid"), ref, 1e-5, "pixel_mlp")
+
+
 def test_pool_and_vec_mlp(dev):
     from isr2_amd import ops
     x = rnd(2, 37, 41, 180, dev=dev, seed=30)
