@@ -172,3 +172,21 @@ def test_image_conversions_bit_exact(dev):
     got = ops.f32_to_u8_image(torch.from_numpy(f).to(dev)).cpu().numpy()
     ref = (np.clip(f[0], 0, 1).transpose(1, 2, 0) * 255.0).round().astype(np.uint8)
     assert got.dtype == np.uint8 and np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("hw", [(200, 168), (272, 204)])
+def test_stream_schedule_is_bit_exact_on_ragged_sizes(dev, hip_model, hw):
+    """The three-stream schedule (experts side by side, LR-only fusion work behind NAFNet) must not change a single bit
+    relative to the serial schedule, also on sizes that need reflect / zero padding (a kernel that read not-yet-visible or
+    uninitialised memory showed up exactly here during development)."""
+    lr = torch.from_numpy(np.random.default_rng(hw[0]).random((1, 3, hw[0], hw[1]), dtype=np.float32)).to(dev)
+    flag = hip_model.multi_stream
+    try:
+        hip_model.multi_stream = False
+        a = hip_model(lr).clone()
+        hip_model.multi_stream = True
+        b = hip_model(lr).clone()
+        c = hip_model(lr).clone()
+    finally:
+        hip_model.multi_stream = flag
+    assert torch.equal(a, b) and torch.equal(a, c)
