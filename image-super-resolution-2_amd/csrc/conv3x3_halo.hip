@@ -18,6 +18,7 @@ struct HaloParams {
   const float* in; const unsigned char* w; const float* bias; const float* mul; const float* res; float* out;
   int B, H, W, Cin, ldi, Cout, ldo, ldr, nchunk, tiles_x, tiles_y, nblk, act, shuffle;
   float alpha;
+  float* pool_part;   // optional [workgroups][Cout padded to nblk*BN]: per-workgroup channel sums of the stored values
 };
 
 #define HX_ROW 272
@@ -180,9 +181,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int n = n0 + wc * TN + j * 32 + l31;
-      if (n >= p.Cout) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
-      const float mv = (p.mul ? p.mul[n] : 1.f) * p.alpha;
+      const bool nok = n < p.Cout;         // (no early `continue`: every wave reaches the pooling barriers below)
+      const int nc = nok ? n : 0;
+      const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+      const float mv = ((nok && p.mul) ? p.mul[n] : 1.f) * p.alpha;
+      float psum = 0.f;                    // this lane's channel, summed over the pixels of the wave's m-tiles
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         long long oidx[16];
@@ -193,27 +196,55 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
         for (int r = 0; r < 16; ++r) {
           const int mrow = (r & 3) + 8 * (r >> 2) + 4 * hh;
           const int oy = ry0 + (mrow >> 4), ox = x0 + (mrow & 15);
-          okp[r] = oy < p.H && ox < p.W;
+          okp[r] = nok && oy < p.H && ox < p.W;
           if (p.shuffle == 2) {              // fused PixelShuffle(2): channel n = 4 co + 2 sy + sx -> pixel (2 oy + sy, 2 ox + sx)
-            const int co = n >> 2, sy = (n >> 1) & 1, sx = n & 1;
+            const int co = nc >> 2, sy = (nc >> 1) & 1, sx = nc & 1;
             const long long pix = okp[r] ? ((long long)(b * 2 * p.H + 2 * oy + sy) * (2 * p.W) + 2 * ox + sx) : 0;
             oidx[r] = pix * p.ldo + co;
             rv[r] = has_res ? p.res[pix * p.ldr + co] : 0.f;
           } else {
             const long long pix = okp[r] ? ((long long)(b * p.H + oy) * p.W + ox) : 0;
-            oidx[r] = pix * p.ldo + n;
-            rv[r] = has_res ? p.res[pix * p.ldr + n] : 0.f;
+            oidx[r] = pix * p.ldo + nc;
+            rv[r] = has_res ? p.res[pix * p.ldr + nc] : 0.f;
           }
         }
         if (ry0 + 1 < p.H && x0 + 15 < p.W) {
+          if (nok) {                         // one exec mask for the whole tile
 #pragma unroll
-          for (int r = 0; r < 16; ++r) p.out[oidx[r]] = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
+            for (int r = 0; r < 16; ++r) {
+              const float v = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
+              p.out[oidx[r]] = v;
+              psum += v;
+            }
+          }
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (okp[r]) p.out[oidx[r]] = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
+            if (okp[r]) {
+              const float v = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
+              p.out[oidx[r]] = v;
+              psum += v;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);   // one tile at a time: do not interleave the address / residual work of all MI*NI tiles
+      }
+      // global-average-pool partials of the output (hat_arch.py:50 ChannelAttention pools exactly this tensor): the lane's
+      // channel over its wave's pixels -> both lane halves -> the WM waves of the workgroup (LDS) -> one value per channel
+      if (p.pool_part) {
+        psum += __shfl_xor(psum, 32);
+        float* ps = reinterpret_cast<float*>(smem);              // [WM][BN]: staging buffers are idle in the epilogue
+        if (j == 0) __syncthreads();                              // (first use: every wave has left the tap loop)
+        if (hh == 0) ps[wr * BN + wc * TN + j * 32 + l31] = psum;
+      }
+    }
+    if (p.pool_part) {
+      __syncthreads();
+      const float* ps = reinterpret_cast<const float*>(smem);
+      for (int c = threadIdx.x; c < BN; c += NT) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) sacc += ps[w * BN + c];
+        p.pool_part[(long long)blockIdx.x * BN + c] = sacc;
       }
     }
   }
@@ -256,10 +287,18 @@ extern "C" long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn) {
   return (long long)((Cout + bn - 1) / bn) * ((Cin + 63) / 64) * 9 * (64 / wk) * slot;
 }
 
+// number of workgroups ( = rows of pool_partials, each nblk... see below) for (B, H, W, Cout, bn): rows x row length
+extern "C" long long ff_conv3x3_halo_pool_rows(int B, int H, int W, int Cout, int bn) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (bn != 32 && bn != 64 && bn != 128 && bn != 192)) return -1;
+  const int th = bn == 128 ? 8 : 16;                           // pixel rows per workgroup (launch table below)
+  return (long long)B * ((H + th - 1) / th) * ((W + 15) / 16) * ((Cout + bn - 1) / bn);
+}
+
 extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const float* bias, const float* mul,
                                const float* res, int ldr, float* out, int ldo, int B, int H, int W, int Cin, int Cout,
-                               int act, float alpha, int shuffle, void* stream) {
+                               int act, float alpha, int shuffle, float* pool_partials, void* stream) {
   FF_CHECK_ARG(in && w_img && out, "ff_conv3x3_halo: null pointer");
+  FF_CHECK_ARG(!pool_partials || (shuffle == 0 && Cout <= bn), "ff_conv3x3_halo: pool partials need Cout <= bn and no pixel shuffle");
   FF_CHECK_ARG(shuffle == 0 || (shuffle == 2 && Cout % 4 == 0), "ff_conv3x3_halo: shuffle must be 0 or 2 (Cout %% 4 == 0)");
   FF_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "ff_conv3x3_halo: bad dims");
   FF_CHECK_ARG(Cin % 4 == 0 && ldi % 4 == 0 && ldi >= Cin && (((uintptr_t)in) & 15) == 0, "ff_conv3x3_halo: input rows must be 16-byte aligned, Cin %% 4 == 0");
@@ -270,7 +309,7 @@ extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int 
   HaloParams p;
   p.in = in; p.w = (const unsigned char*)w_img; p.bias = bias; p.mul = mul; p.res = res; p.out = out;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.ldi = ldi; p.Cout = Cout; p.ldo = ldo; p.ldr = ldr;
-  p.nchunk = (Cin + 63) / 64; p.act = act; p.alpha = alpha; p.shuffle = shuffle;
+  p.nchunk = (Cin + 63) / 64; p.act = act; p.alpha = alpha; p.shuffle = shuffle; p.pool_part = pool_partials;
   hipStream_t st = (hipStream_t)stream;
   switch (bn) {
     // 16x16-pixel workgroups of 8 waves (two per SIMD: one wave's LDS reads and waits hide behind the

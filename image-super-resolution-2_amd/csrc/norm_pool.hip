@@ -130,22 +130,22 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
 }
 
 // stage 2: 64 channels x 4 partial-lanes per workgroup, 4 independent accumulators per thread
-__global__ __launch_bounds__(256) void pool_final_kernel(const float* __restrict__ part, int nch, int C, float invP,
+__global__ __launch_bounds__(256) void pool_final_kernel(const float* __restrict__ part, int nch, int C, int ldp, float invP,
                                                          float* __restrict__ out) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < C) {
-    const float* pp = part + (long long)b * nch * C + c;
+    const float* pp = part + (long long)b * nch * ldp + c;
     int i = r;
     for (; i + 12 < nch; i += 16) {
-      s0 += pp[(long long)i * C];
-      s1 += pp[(long long)(i + 4) * C];
-      s2 += pp[(long long)(i + 8) * C];
-      s3 += pp[(long long)(i + 12) * C];
+      s0 += pp[(long long)i * ldp];
+      s1 += pp[(long long)(i + 4) * ldp];
+      s2 += pp[(long long)(i + 8) * ldp];
+      s3 += pp[(long long)(i + 12) * ldp];
     }
-    for (; i < nch; i += 4) s0 += pp[(long long)i * C];
+    for (; i < nch; i += 4) s0 += pp[(long long)i * ldp];
   }
   red[r][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -169,8 +169,17 @@ extern "C" int ff_pool_mean(const float* in, int ld, int B, long long P, int C, 
   } else {
     hipLaunchKernelGGL(pool_partial_kernel, dim3(nch, B), dim3(256), 0, st, in, ld, P, C, ppc, work);
   }
-  hipLaunchKernelGGL(pool_final_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, work, nch, C, 1.0f / (float)P, out);
+  hipLaunchKernelGGL(pool_final_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, work, nch, C, C, 1.0f / (float)P, out);
   FF_LAUNCH_CHECK("ff_pool_mean");
+  return FF_OK;
+}
+
+// second stage alone: out[c] = inv_count * sum_r part[r][c] over `rows` rows of pitch ld (per-workgroup partials written by a
+// producer kernel's epilogue, e.g. ff_conv3x3_halo pool_partials)
+extern "C" int ff_pool_finish(const float* part, int rows, int ld, int C, float inv_count, float* out, void* stream) {
+  FF_CHECK_ARG(part && out && rows > 0 && C > 0 && ld >= C, "ff_pool_finish: bad args");
+  hipLaunchKernelGGL(pool_final_kernel, dim3((C + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream, part, rows, C, ld, inv_count, out);
+  FF_LAUNCH_CHECK("ff_pool_finish");
   return FF_OK;
 }
 

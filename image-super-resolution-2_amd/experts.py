@@ -150,8 +150,8 @@ class HatHIP:
                         kwin=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, heads=self.heads, d=d, scale=d ** -0.5,
                         rel_table=blk["rel"] if _REL_BIAS else None)
         c1 = ops.conv2d(xn, *blk["cab0"], ksize=(3, 3), pad=(1, 1), act="gelu")
-        c2 = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1))
-        gate = ops.vec_mlp(ops.pool_mean(c2), *blk["ca1"], "relu", *blk["ca2"], "sigmoid", post=self.conv_scale)
+        c2, c2mean = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1), want_pool=True)   # pool from the conv epilogue
+        gate = ops.vec_mlp(c2mean, *blk["ca1"], "relu", *blk["ca2"], "sigmoid", post=self.conv_scale)
         if _fast():                                                # shortcut + conv_x*conv_scale + proj(attention), one launch
             x = ops.token_linear(att, _tl(blk, "proj"), res=x, res2=c2, res2_scale=gate.reshape(-1))
         else:

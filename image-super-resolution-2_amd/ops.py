@@ -187,8 +187,10 @@ def _nhwc(t: T, name: str):
 
 def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1), pad=(0, 0), act=None,
            res: Optional[T] = None, mul: Optional[T] = None, alpha: float = 1.0, shuffle: int = 0,
-           out: Optional[T] = None, tile_hint: int = 0, dynamic_w: bool = False) -> T:
-    """x [B,H,W,Cin] (rows view), w packed [Cout, KH*KW*Cin] -> [B,Ho,Wo,Cout] (or pixel-shuffled)."""
+           out: Optional[T] = None, tile_hint: int = 0, dynamic_w: bool = False, want_pool: bool = False):
+    """x [B,H,W,Cin] (rows view), w packed [Cout, KH*KW*Cin] -> [B,Ho,Wo,Cout] (or pixel-shuffled).
+    want_pool (B == 1): also return the global average pool [1, Cout] of the output -> (out, pooled); the LDS-resident 3x3
+    kernel produces it from its epilogue, any other path falls back to ff_pool_mean on the output."""
     xp, ldi, B, H, W, Cin = _nhwc(x, "conv2d.x")
     KH, KW = ksize
     Cout = w.shape[0]
@@ -221,8 +223,17 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
             bn = _prep.halo_bn(Cout)
             img = (_prep.pack_conv3x3_halo(w, Cin, bn), bn)
             w._ff_halo = img
+        part = None
+        if want_pool and B == 1 and shuffle == 0 and Cout <= img[1]:
+            prow = int(_L().ff_conv3x3_halo_pool_rows(B, H, W, Cout, img[1]))
+            part = torch.empty((prow, img[1]), device=x.device, dtype=torch.float32)
         _lib.check(_L().ff_conv3x3_halo(xp, ldi, img[0].data_ptr(), img[1], _ptr(bias), _ptr(mul), rp, ldr, op, ldo, B, H, W,
-                                        Cin, Cout, ACT[act], float(alpha), shuffle, _stream()))
+                                        Cin, Cout, ACT[act], float(alpha), shuffle, _ptr(part), _stream()))
+        if part is not None:
+            pooled = torch.empty((1, Cout), device=x.device, dtype=torch.float32)
+            _lib.check(_L().ff_pool_finish(part.data_ptr(), part.shape[0], img[1], Cout, 1.0 / float(H * W), pooled.data_ptr(), _stream()))
+            _note(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, 4.0 * (_numel(x, w, out, res)))
+            return out, pooled
     else:
         aligned = (ldi % 4 == 0) and (xp % 16 == 0)
         hi, lo, Kp, Cp, _ = _split_weight(w, dynamic_w, Cin if aligned else 0)
@@ -231,6 +242,8 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
                                         pad[0], pad[1], ACT[act], float(alpha), shuffle, GEMM_MODES[_GEMM_MODE], tile_hint,
                                         _stream()))
     _note(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, 4.0 * (_numel(x, w, out, res)))
+    if want_pool:
+        return out, pool_mean(out)
     return out
 
 

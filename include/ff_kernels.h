@@ -101,9 +101,13 @@ int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long long M, int 
  * [ceil(Cout/bn)][ceil(Cin/64)][9 taps][bn rows x (64 hi | 64 lo | 8 pad) bf16, padded to 1 KiB], of
  * ff_conv3x3_halo_weight_bytes(Cout, Cin, bn) bytes (-1: bad arguments).  Needs Cin % 4 == 0, 16-byte aligned rows. */
 long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn);
+/* pool_partials (optional, Cout <= bn, no shuffle): [ff_conv3x3_halo_pool_rows(B,H,W,Cout,bn)][bn] per-workgroup channel sums of the
+ * stored output, finished by ff_pool_finish (the global average pool of hat_arch.py:50 without re-reading the tensor). */
+long long ff_conv3x3_halo_pool_rows(int B, int H, int W, int Cout, int bn);
+int ff_pool_finish(const float* part, int rows, int ld, int C, float inv_count, float* out, void* stream);
 int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const float* bias, const float* mul,
                     const float* res, int ldr, float* out, int ldo, int B, int H, int W, int Cin, int Cout,
-                    int act, float alpha, int shuffle, void* stream);
+                    int act, float alpha, int shuffle, float* pool_partials, void* stream);
 
 /* Token-stationary linear layer for K <= 192 (csrc/token_linear.hip), bf16x3 MFMA:
  *   out = res + res2*res2_scale[n] + act( LayerNorm?(x) . W^T + bias )        (gamma == NULL: no LayerNorm)

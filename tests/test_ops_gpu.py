@@ -115,6 +115,10 @@ def test_conv3x3_halo_matches_torch(dev, B, H, W, Cin, Cout, act):
         f = {"gelu": F.gelu, "relu": F.relu, "sigmoid": torch.sigmoid, "lrelu": lambda t: F.leaky_relu(t, 0.01), None: lambda t: t}[act]
         ref = res + 0.7 * mul * f(F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)).permute(0, 2, 3, 1)
         close(out, ref, GEMM_TOL["bf16x3"], "conv3x3 halo")
+        if B == 1:                       # global average pool of the stored output from the same launch (epilogue partials)
+            out3, pooled = ops.conv2d(x, wp, b, ksize=(3, 3), pad=(1, 1), act=act, res=res, mul=mul, alpha=0.7, want_pool=True)
+            assert torch.equal(out3, out)
+            close(pooled, out.mean(dim=(1, 2)), 2e-5, "pooled conv output")
         ops.set_halo(False)
         out2 = ops.conv2d(x, pack_conv(w), b, ksize=(3, 3), pad=(1, 1), act=act, res=res, mul=mul, alpha=0.7)
         close(out, out2, GEMM_TOL["bf16x3"], "halo vs implicit GEMM")
