@@ -195,32 +195,12 @@ extern "C" long long ff_pool_mean_workspace(int B, long long P, int C) {
 __global__ __launch_bounds__(256) void vec_mlp_kernel(const float* __restrict__ in, int Cin, const float* __restrict__ W1,
                                                       const float* __restrict__ b1, int Ch, int act1,
                                                       const float* __restrict__ W2, const float* __restrict__ b2,
-                                                      int Cout, int act2, float post, float* __restrict__ out,
-                                                      int part_rows, int part_ld, float part_scale) {
+                                                      int Cout, int act2, float post, float* __restrict__ out) {
   extern __shared__ float sm[];
   float* xin = sm;            // [Cin]
   float* hid = sm + Cin;      // [Ch]
   const int b = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (part_rows > 0) {
-    // `in` holds per-workgroup partial sums [part_rows][part_ld] of a producer's epilogue (ff_conv3x3_halo pool_partials):
-    // finish the average pool here instead of in a launch of its own (64 channels x 4 row-lanes per pass)
-    __shared__ float red[4][64];
-    for (int c0 = 0; c0 < Cin; c0 += 64) {
-      const int c = c0 + lane;
-      float s0 = 0.f, s1 = 0.f;
-      if (c < Cin) {
-        int i = wid;
-        for (; i + 4 < part_rows; i += 8) { s0 += in[(long long)i * part_ld + c]; s1 += in[(long long)(i + 4) * part_ld + c]; }
-        for (; i < part_rows; i += 4) s0 += in[(long long)i * part_ld + c];
-      }
-      red[wid][lane] = s0 + s1;
-      __syncthreads();
-      if (wid == 0 && c < Cin) xin[c] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * part_scale;
-      __syncthreads();
-    }
-  } else {
-    for (int i = threadIdx.x; i < Cin; i += 256) xin[i] = in[(long long)b * Cin + i];
-  }
+  for (int i = threadIdx.x; i < Cin; i += 256) xin[i] = in[(long long)b * Cin + i];
   __syncthreads();
   if (W2) {
     for (int j = wid; j < Ch; j += 4) {
@@ -247,17 +227,15 @@ __global__ __launch_bounds__(256) void vec_mlp_kernel(const float* __restrict__ 
 }
 
 extern "C" int ff_vec_mlp(const float* in, int B, int Cin, const float* W1, const float* b1, int Ch, int act1,
-                          const float* W2, const float* b2, int Cout, int act2, float post, float* out, int part_rows, int part_ld,
-                          float part_scale, void* stream) {
+                          const float* W2, const float* b2, int Cout, int act2, float post, float* out, void* stream) {
   FF_CHECK_ARG(in && W1 && out, "ff_vec_mlp: null pointer");
-  FF_CHECK_ARG(part_rows == 0 || (part_rows > 0 && B == 1 && part_ld >= Cin), "ff_vec_mlp: partial-sum input needs B == 1 and part_ld >= Cin");
   FF_CHECK_ARG(B > 0 && Cin > 0 && Ch > 0 && (Cin + Ch) * 4 <= 48 * 1024, "ff_vec_mlp: bad dims");
   FF_CHECK_ARG(!W2 || Cout > 0, "ff_vec_mlp: bad Cout");
   const int nout = W2 ? Cout : Ch;
   int gx = (nout + 3) / 4;
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(vec_mlp_kernel, dim3(gx, B), dim3(256), (size_t)(Cin + Ch) * 4, (hipStream_t)stream, in, Cin, W1, b1, Ch,
-                     act1, W2, b2, Cout, act2, post, out, part_rows, part_ld, part_scale);
+                     act1, W2, b2, Cout, act2, post, out);
   FF_LAUNCH_CHECK("ff_vec_mlp");
   return FF_OK;
 }

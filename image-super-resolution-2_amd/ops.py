@@ -189,9 +189,8 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
            res: Optional[T] = None, mul: Optional[T] = None, alpha: float = 1.0, shuffle: int = 0,
            out: Optional[T] = None, tile_hint: int = 0, dynamic_w: bool = False, want_pool: bool = False):
     """x [B,H,W,Cin] (rows view), w packed [Cout, KH*KW*Cin] -> [B,Ho,Wo,Cout] (or pixel-shuffled).
-    want_pool (B == 1): also return the global average pool of the output -> (out, pooled).  The LDS-resident 3x3 kernel emits
-    per-workgroup partial sums from its epilogue (pooled is then a PoolPartials: vec_mlp consumes it directly, .mean() finishes
-    it); any other path returns ff_pool_mean of the output ([1, Cout])."""
+    want_pool (B == 1): also return the global average pool [1, Cout] of the output -> (out, pooled); the LDS-resident 3x3
+    kernel produces it from its epilogue, any other path falls back to ff_pool_mean on the output."""
     xp, ldi, B, H, W, Cin = _nhwc(x, "conv2d.x")
     KH, KW = ksize
     Cout = w.shape[0]
@@ -231,8 +230,10 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
         _lib.check(_L().ff_conv3x3_halo(xp, ldi, img[0].data_ptr(), img[1], _ptr(bias), _ptr(mul), rp, ldr, op, ldo, B, H, W,
                                         Cin, Cout, ACT[act], float(alpha), shuffle, _ptr(part), _stream()))
         if part is not None:
+            pooled = torch.empty((1, Cout), device=x.device, dtype=torch.float32)
+            _lib.check(_L().ff_pool_finish(part.data_ptr(), part.shape[0], img[1], Cout, 1.0 / float(H * W), pooled.data_ptr(), _stream()))
             _note(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, 4.0 * (_numel(x, w, out, res)))
-            return out, PoolPartials(part, Cout, 1.0 / float(H * W))
+            return out, pooled
     else:
         aligned = (ldi % 4 == 0) and (xp % 16 == 0)
         hi, lo, Kp, Cp, _ = _split_weight(w, dynamic_w, Cin if aligned else 0)
@@ -412,36 +413,16 @@ def pool_mean(x: T) -> T:
     return out
 
 
-class PoolPartials:
-    """Per-workgroup channel sums [rows, ld] of a producer's epilogue + the scale that turns their column sums into the mean;
-    vec_mlp finishes the pool itself when handed one of these (mean() runs ff_pool_finish for any other consumer)."""
-
-    def __init__(self, part: T, C: int, scale: float):
-        self.part, self.C, self.scale = part, C, scale
-
-    def mean(self) -> T:
-        out = torch.empty((1, self.C), device=self.part.device, dtype=torch.float32)
-        _lib.check(_L().ff_pool_finish(self.part.data_ptr(), self.part.shape[0], self.part.shape[1], self.C, float(self.scale),
-                                       out.data_ptr(), _stream()))
-        return out
-
-
-def vec_mlp(v, W1: T, b1: Optional[T], act1, W2: Optional[T] = None, b2: Optional[T] = None, act2=None,
+def vec_mlp(v: T, W1: T, b1: Optional[T], act1, W2: Optional[T] = None, b2: Optional[T] = None, act2=None,
             post: float = 1.0) -> T:
-    prow, pld, pscale = 0, 0, 0.0
-    if isinstance(v, PoolPartials):
-        prow, pld, pscale = v.part.shape[0], v.part.shape[1], v.scale
-        B, Cin = 1, v.C
-        v = v.part
-    else:
-        B, Cin = v.shape
+    B, Cin = v.shape
     Ch = W1.shape[0]
     Cout = W2.shape[0] if W2 is not None else Ch
     if W1.shape[1] != Cin or (W2 is not None and W2.shape[1] != Ch):
         raise _lib.FFError("vec_mlp: weight shape mismatch")
     out = torch.empty((B, Cout), device=v.device, dtype=torch.float32)
     _lib.check(_L().ff_vec_mlp(v.data_ptr(), B, Cin, W1.data_ptr(), _ptr(b1), Ch, ACT[act1], _ptr(W2), _ptr(b2), Cout,
-                               ACT[act2], float(post), out.data_ptr(), int(prow), int(pld), float(pscale), _stream()))
+                               ACT[act2], float(post), out.data_ptr(), _stream()))
     return out
 
 

@@ -146,12 +146,9 @@ int ff_pool_mean(const float* in, int ld, int B, long long P, int C, float* out,
 long long ff_pool_mean_workspace(int B, long long P, int C);
 
 /* out[b] = act2(W2 . act1(W1 . in[b] + b1) + b2) * post; W2 == NULL -> single layer act1(W1.in+b1)*post.
- * The 1x1-conv MLPs that follow the pools (hat_arch.py:51-54; dat_arch.py:412-416,604-608; nafnet_arch.py:87).
- * part_rows > 0 (B == 1): `in` is instead [part_rows][part_ld] partial sums (ff_conv3x3_halo pool_partials) and the input vector
- * is part_scale * their column sums -- the average pool is finished inside this launch. */
+ * The 1x1-conv MLPs that follow the pools (hat_arch.py:51-54; dat_arch.py:412-416,604-608; nafnet_arch.py:87). */
 int ff_vec_mlp(const float* in, int B, int Cin, const float* W1, const float* b1, int Ch, int act1, const float* W2,
-               const float* b2, int Cout, int act2, float post, float* out, int part_rows, int part_ld,
-               float part_scale, void* stream);
+               const float* b2, int Cout, int act2, float post, float* out, void* stream);
 
 /* Depth-wise conv, NHWC, zero padding, weights tap-major [KH*KW][C]:
  *   out = act((sum w*x + bias) * post_scale + post_shift) * mul_in[pixel][c]     (mul_in may be NULL)

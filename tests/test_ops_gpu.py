@@ -118,16 +118,7 @@ def test_conv3x3_halo_matches_torch(dev, B, H, W, Cin, Cout, act):
         if B == 1:                       # global average pool of the stored output from the same launch (epilogue partials)
             out3, pooled = ops.conv2d(x, wp, b, ksize=(3, 3), pad=(1, 1), act=act, res=res, mul=mul, alpha=0.7, want_pool=True)
             assert torch.equal(out3, out)
-            if Cout <= 192:
-                assert isinstance(pooled, ops.PoolPartials)                  # one n-block: partial sums from the epilogue
-                close(pooled.mean(), out.mean(dim=(1, 2)), 2e-5, "pooled conv output")
-            else:
-                close(pooled, out.mean(dim=(1, 2)), 2e-5, "pooled conv output (separate pass)")
-            W1, b1 = rnd(6, Cout, dev=dev, seed=65, scale=0.2), rnd(6, dev=dev, seed=66, scale=0.1)
-            W2, b2 = rnd(Cout, 6, dev=dev, seed=67, scale=0.3), rnd(Cout, dev=dev, seed=68, scale=0.1)
-            gate = ops.vec_mlp(pooled, W1, b1, "relu", W2, b2, "sigmoid", post=0.01)       # pool finished inside the MLP launch
-            gref = torch.sigmoid(F.linear(F.relu(F.linear(out.mean(dim=(1, 2)), W1, b1)), W2, b2)) * 0.01
-            close(gate, gref, 2e-5, "vec_mlp from pool partials")
+            close(pooled, out.mean(dim=(1, 2)), 2e-5, "pooled conv output")
         ops.set_halo(False)
         out2 = ops.conv2d(x, pack_conv(w), b, ksize=(3, 3), pad=(1, 1), act=act, res=res, mul=mul, alpha=0.7)
         close(out, out2, GEMM_TOL["bf16x3"], "halo vs implicit GEMM")
