@@ -190,3 +190,17 @@ def test_stream_schedule_is_bit_exact_on_ragged_sizes(dev, hip_model, hw):
     finally:
         hip_model.multi_stream = flag
     assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_config3_tiled_image_geometry(dev, hip_model):
+    """a 510x339 LR image cut into 256-pixel tiles with 32 overlap (x in {0,224,254}, y in {0,83}: six
+    tiles), blended on the device by ff_tile_accum / ff_tile_normalize -- against the oracle's restatement of the reference
+    blending (io.py:82-121) fed with the same per-tile outputs."""
+    import models.team29_FreqFusion.io as plug
+    from oracle import freqfusion_oracle as O
+    assert plug._tile_positions(510, 256, 224) == [0, 224, 254] and plug._tile_positions(339, 256, 224) == [0, 83]
+    lr = torch.from_numpy(np.random.default_rng(33).random((1, 3, 339, 510), dtype=np.float32))
+    got = plug._tiled_forward(hip_model, lr.to(dev), tile_size=256, overlap=32, scale=4, device=dev).cpu()
+    ref = O.tiled_forward(lambda t: hip_model(t.to(dev)).cpu(), lr, tile=256, overlap=32, scale=4)
+    assert tuple(got.shape) == (1, 3, 1356, 2040)
+    assert (got - ref).abs().max().item() < 2e-6
