@@ -1,6 +1,9 @@
 """Headline benchmark: output MPix/s of the FreqFusion x4 full 3-expert forward on 256x256 LR tiles.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either the driver launches one rank per GPU (torch.distributed.run: RANK / WORLD_SIZE set), or -- when called plainly --
+this script starts N fresh child ranks of itself before touching any GPU and relays rank 0's JSON line.
 
 One process per GPU.  A step = one pass of the hot path (HAT-L + DAT + NAFNet-SR + fusion stack) over
 one synthetic 256x256 LR tile per GPU (BASELINE.json configs[1]); tiles are independent, so ranks
@@ -77,19 +80,92 @@ def broadcast_weights(rank: int, world: int, dev):
     return sd, time.perf_counter() - t0
 
 
-def cpu_baseline(sd, threads: int):
-    """The CPU oracle (a port of the reference's PyTorch eval path, pinned to it by golden fixtures) timed on
-    this host's cores on a bounded sample: one 64x64 LR tile = 1/16 of the 256x256 workload."""
+def cpu_model_name() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, threads: int, tile: int):
+    """The CPU oracle (a port of the reference's PyTorch eval path, pinned to it by golden fixtures) timed on this host's
+    cores on THE SAME workload as the GPU step: one warm-up on a 64x64 tile (loads the code paths), then one timed
+    `tile` x `tile` LR tile (BASELINE.md section 3 / SURVEY 8d)."""
     from oracle import freqfusion_oracle as O
     torch.set_num_threads(threads)
-    lr = make_tile(3, 64)
     cpu_sd = {k: v.detach().cpu() for k, v in sd.items()}
+    O.forward(cpu_sd, make_tile(3, 64))
+    lr = make_tile(100, tile)
     t0 = time.perf_counter()
     O.forward(cpu_sd, lr)
     dt = time.perf_counter() - t0
-    return {"value": (256 * 256 / 1e6) / dt, "unit": "output MPix/s", "cores": threads, "kind": "port",
-            "sample": "CPU oracle (PyTorch fp32 restatement of the reference eval path) on one 64x64 LR tile -> 256x256, "
-                      f"{dt:.1f} s wall; 1/16 of the GPU workload's tile"}
+    return {"value": ((4 * tile) ** 2 / 1e6) / dt, "unit": "output MPix/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model_name(), "seconds_per_tile": dt,
+            "sample": f"CPU oracle (PyTorch fp32 restatement of the reference eval path) on one {tile}x{tile} LR tile -> "
+                      f"{4 * tile}x{4 * tile} (the GPU step's own workload), 1 warm-up on 64x64 + 1 timed tile, {dt:.1f} s wall on "
+                      f"{threads} threads"}
+
+
+def csrc_fingerprint() -> str:
+    """Content hash of the kernel sources: a PMC traffic file is only quoted while it describes these kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "image-super-resolution-2_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def golden_psnr(model, dev):
+    """PSNR of this model's output on bench tile 100 against the REFERENCE's output on the same tile (65 536 samples of the
+    committed golden tests/golden/t256_nat.npz, generated from the imported reference)."""
+    path = os.path.join(ROOT, "tests", "golden", "t256_nat.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    out = model(torch.from_numpy(g["lr"]).to(dev)).reshape(-1).cpu()
+    got = out[torch.from_numpy(g["big/final/idx"])].double()
+    mse = float(((got - torch.from_numpy(g["big/final/val"]).double()) ** 2).mean())
+    return 10.0 * float(np.log10(1.0 / max(mse, 1e-30)))
+
+
+def time_mode(mode: str, sd, dev, lr, steps: int):
+    """ms per step (HIP-graph replay) and golden PSNR of another contraction mode, for the `extra` block."""
+    from isr2_amd import ops
+    from isr2_amd.model import FreqFusionHIP
+    old = ops.gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        m = FreqFusionHIP(sd, dev)
+        psnr = golden_psnr(m, dev) if tuple(lr.shape[-2:]) == (TILE, TILE) else None
+        m.graphed(lr)
+        m.graphed(lr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.graphed(lr)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        del m
+        torch.cuda.empty_cache()
+    finally:
+        ops.set_gemm_mode(old)
+    return {"ms_per_step": ms, "output_MPix_s": (4 * lr.shape[-1]) ** 2 / 1e6 / (ms * 1e-3), "psnr_vs_reference_golden_dB": psnr}
+
+
+def self_spawn(args) -> int:
+    """`python bench.py --gpus N` called plainly: start N fresh ranks of this script (no GPU call has happened in this process)."""
+    from isr2_amd.parallel import spawn_ranks
+    ndev = torch.cuda.device_count()                          # counting devices does not initialise the GPU
+    if os.environ.get("FF_DIST_BACKEND", "nccl") == "nccl" and args.gpus > ndev:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible on this node (one rank per GPU over RCCL)", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    return spawn_ranks(cmd, args.gpus)
 
 
 def main():
@@ -99,15 +175,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="time the eager Python launch loop instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the f32 / plain-bf16 side measurements")
     ap.add_argument("--tile", type=int, default=TILE)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_spawn(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     # one rank per GPU.  (Rehearsal on a box with fewer GPUs than ranks: FF_DIST_BACKEND=gloo lets several ranks share a
     # card -- RCCL refuses that -- so the whole N>1 code path can be exercised on one MI355X; never used for a result.)
     backend = os.environ.get("FF_DIST_BACKEND", "nccl")
@@ -229,10 +307,17 @@ def main():
             return int(m.group(1)) if m else -1
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_v*.json")), key=lambda f: (os.path.basename(f)[:3], _ver(f)))
         tdoc = None
+        fp = csrc_fingerprint()
         if tfiles:                                      # PMC counters come from separate rocprofv3 passes (tools/pmc_traffic.py)
             tdoc = json.load(open(tfiles[-1]))
-            traffic = tdoc["conv_igemm_all_variants"]["hbm_MB_per_launch"] * 1e6
-            tnote = "HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/" + os.path.basename(tfiles[-1])
+            if tdoc.get("csrc_fingerprint") != fp:      # the counters describe other kernels than the ones just timed
+                tnote = (f"profiles/{os.path.basename(tfiles[-1])} was collected for csrc {tdoc.get('csrc_fingerprint')}, the "
+                         f"kernels timed here are {fp}: stale, not quoted")
+                tdoc = None
+            else:
+                traffic = tdoc["conv_igemm_all_variants"]["hbm_MB_per_launch"] * 1e6
+                tnote = ("HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/" + os.path.basename(tfiles[-1])
+                         + f" (csrc {fp}, git {tdoc.get('git', 'n/a')})")
         roof = {"bound": "mfma", "kernel": "ff_conv2d*: conv_igemm_bf16_kernel (all tile variants) + conv3x3_halo_kernel (f32 mode: conv_igemm_kernel) -- every Conv2d and every Linear with K > 192",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": traffic, "traffic_note": tnote,
@@ -251,6 +336,15 @@ def main():
             return {"kernel": name, "bound": bound, "achieved": ach, "peak": peak_v, "unit": unit, "frac": ach / peak_v,
                     "traffic": tr, "launches_per_tile": a[0], "avg_launch_us": 1e3 * a[1] / a[0],
                     "algorithmic_bytes_per_launch": a[3] / a[0], "algorithmic_gflop_per_launch": a[2] / a[0] / 1e9}
+        hbm_gb = None
+        if tdoc and tdoc.get("forwards"):
+            hbm_gb = tdoc["whole_forward"]["hbm_MB_total"] / tdoc["forwards"] / 1e3
+        step_s = elapsed / args.steps
+        roof["whole_path"] = {"hbm_GB_per_tile": hbm_gb, "TB_s": (hbm_gb / 1e3 / step_s) if hbm_gb else None,
+                              "algorithmic_TFLOPs": flop_per_tile / step_s / 1e12,
+                              "compulsory_GB": 0.689 + 4 * 3 * (tile * tile + 16 * tile * tile) / 1e9,
+                              "note": "hbm_GB_per_tile = PMC (2*FETCH_SIZE+WRITE_SIZE) summed over every kernel of one forward; "
+                                      "compulsory = fp32 weights read once + LR in + SR out"}
         roof["other_kernels"] = [r for r in (
             _fam("token_linear", "hbm", 8000.0, "GB/s", "token_linear_all_variants"),
             _fam("window_attn", "mfma", peak, "TFLOP/s", "window_attn_all_variants"),
@@ -273,10 +367,20 @@ def main():
             "path_tflops": world * args.steps * flop_per_tile / elapsed / 1e12,
             "roofline": roof, "stage_ms_per_tile": stages, "kernel_breakdown_ms_per_tile": breakdown,
         }
+        if world == 1 and not args.no_extra:
+            log("side measurements: f32 and plain-bf16 contraction modes")
+            extra = {"note": "same workload and launch path in the other contraction modes; PSNR is against the REFERENCE's output "
+                             "on bench tile 100 (tests/golden/t256_nat.npz)",
+                     ops.gemm_mode(): {"ms_per_step": line["ms_per_step"], "output_MPix_s": value,
+                                       "psnr_vs_reference_golden_dB": golden_psnr(model, dev) if tile == TILE else None}}
+            for mode in ("f32", "bf16"):
+                if mode != ops.gemm_mode():
+                    extra[mode] = time_mode(mode, sd, dev, lr, max(2, min(args.steps, 5)))
+            line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            log("cpu baseline (oracle, 64x64 tile)")
-            line["cpu_baseline"] = cpu_baseline(sd, host_threads())
-        print(json.dumps(line))
+            log(f"cpu baseline (oracle, {tile}x{tile} tile, {host_threads()} threads)")
+            line["cpu_baseline"] = cpu_baseline(sd, host_threads(), tile)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -382,6 +382,17 @@ class NafnetHIP:
         self.decs = [[blk(f"decoders.{l}.{b}.") for b in range(n)] for l, n in enumerate(dec)]
         self.downs = [(w.conv(f"downs.{l}"), w(f"downs.{l}.bias")) for l in range(len(enc))]
         self.ups = [w(f"ups.{l}.0.weight").reshape(w(f"ups.{l}.0.weight").shape[0], -1).contiguous() for l in range(len(dec))]
+        self._inp = {}
+
+    def _padded_input(self, B: int, Hp: int, Wp: int, dev) -> T:
+        """[B,Hp,Wp,3] buffer whose padding (check_image_size, nafnet_arch.py:220-225: zeros right/bottom) was zeroed ONCE when
+        the buffer was made; the resampler only ever writes the top-left H x W region, so no fill runs per forward.  Kept per
+        shape for the life of the model: a captured HIP graph may hold the address."""
+        key = (B, Hp, Wp, str(dev))
+        buf = self._inp.get(key)
+        if buf is None:
+            buf = self._inp[key] = torch.zeros((B, Hp, Wp, 3), device=dev, dtype=torch.float32)
+        return buf
 
     def block(self, x: T, k: dict) -> T:
         c = x.shape[-1]
@@ -407,7 +418,7 @@ class NafnetHIP:
         H, W = 4 * h, 4 * w
         m = 2 ** len(self.enc_n)
         Hp, Wp = _ceil_to(H, m), _ceil_to(W, m)
-        inp = torch.zeros((1, Hp, Wp, 3), device=lr.device, dtype=torch.float32)
+        inp = self._padded_input(1, Hp, Wp, lr.device)
         ops.resize(lr, (H, W), mode="bicubic", scale_factor=4.0, layout="nchw", out=inp)
         x = ops.conv2d(inp, *self.intro, ksize=(3, 3), pad=(1, 1))
         skips = []

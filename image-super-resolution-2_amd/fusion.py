@@ -204,11 +204,13 @@ class HierFusion:
         self._cat = {}
 
     def _cat_buf(self, h: int, w: int, dev, key: str) -> T:
-        """[1,h,w,76] concat buffer whose channels 73..75 are zero (allocated zeroed once per size; never written again)."""
-        buf = self._cat.get(key)                       # one buffer per role: a new image size replaces it
-        if buf is None or tuple(buf.shape) != (1, h, w, 76) or buf.device != torch.device(dev):
-            buf = torch.zeros((1, h, w, 76), device=dev, dtype=torch.float32)
-            self._cat[key] = buf
+        """[1,h,w,76] concat buffer whose channels 73..75 are zero (allocated zeroed once per size; never written again).
+        One buffer per (role, size), kept for the life of the model: a HIP graph captured at one size keeps its address valid
+        when a forward at another size comes in between."""
+        k = (key, h, w, str(dev))
+        buf = self._cat.get(k)
+        if buf is None:
+            buf = self._cat[k] = torch.zeros((1, h, w, 76), device=dev, dtype=torch.float32)
         return buf
 
     def _stage(self, x: T, name: str) -> T:
@@ -362,7 +364,8 @@ class FusionHIP:
         up = ops.resize(lr_nhwc, (4 * h, 4 * w), mul=self.res_scale)
         return dict(raw=raw, xb=xb, b3=b3, guide=guide, lr_nhwc=lr_nhwc, gates=gates, dif=dif, up=up)
 
-    def forward(self, lr: T, experts: Dict[str, T], taps: Optional[dict] = None, pre: Optional[dict] = None) -> T:
+    def forward(self, lr: T, experts: Dict[str, T], taps: Optional[dict] = None, pre: Optional[dict] = None,
+                out: Optional[T] = None) -> T:
         """lr NCHW [1,3,h,w]; experts: dict of NCHW [1,3,4h,4w] -> SR NCHW [1,3,4h,4w]."""
         _, _, h, w = lr.shape
         dev = lr.device
@@ -388,5 +391,4 @@ class FusionHIP:
         f = ops.mix2(f, pre["up"], clamp01=True)
         if taps is not None:
             taps["fusion.pre_edge"] = f
-        out = self.edge(f)
-        return ops.nhwc_to_nchw(out)
+        return ops.nhwc_to_nchw(self.edge(f), out=out)

@@ -569,10 +569,16 @@ def nchw_to_nhwc(x: T, Hp: Optional[int] = None, Wp: Optional[int] = None, add: 
     return out
 
 
-def nhwc_to_nchw(x: T, H: Optional[int] = None, W: Optional[int] = None, add: Optional[T] = None, clamp01: bool = False) -> T:
+def nhwc_to_nchw(x: T, H: Optional[int] = None, W: Optional[int] = None, add: Optional[T] = None, clamp01: bool = False,
+                 out: Optional[T] = None) -> T:
     xp, ldi, B, Hs, Ws, C = _nhwc(x, "nhwc_to_nchw.x")
     H, W = H or Hs, W or Ws
-    out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, "nhwc_to_nchw.out")
+        if tuple(out.shape) != (B, C, H, W) or not out.is_contiguous():
+            raise _lib.FFError(f"nhwc_to_nchw: out must be a contiguous [{B},{C},{H},{W}] tensor")
     _lib.check(_L().ff_nhwc_to_nchw(xp, out.data_ptr(), B, C, H, W, Hs, Ws, ldi, _ptr(add), int(clamp01), _stream()))
     return out
 

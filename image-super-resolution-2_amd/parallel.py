@@ -64,3 +64,44 @@ def broadcast_state_dict(sd_on_src, spec, rank: int, world: int, device, src: in
     for (n, s, _), off in zip(spec, offs):
         out[n] = flat[off:off + _numel(s)].reshape(tuple(s))
     return out
+
+
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(cmd: List[str], world: int, extra_env: Dict[str, str] = None, timeout: float = None) -> int:
+    """Start `world` fresh child processes of `cmd`, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    in their environment, as torch.distributed.run would set them), wait for all, return the worst exit code.
+    The caller must not have touched the GPU: children are started with subprocess (fork+exec of a process that never
+    initialised HIP), never by re-exec'ing a GPU process.  Rank 0 inherits stdout (its JSON line / progress is the job's);
+    the other ranks' stdout goes to stderr so a single machine-readable line stays on stdout."""
+    import os
+    import subprocess
+    import sys
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
+    worst = 0
+    try:
+        for p in procs:
+            rc = p.wait(timeout=timeout)
+            if rc != 0:
+                worst = worst or rc
+    finally:
+        for p in procs:                      # a rank that failed leaves its peers waiting in a collective: end exactly those PIDs
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    return worst

@@ -5,12 +5,23 @@ Drop-in for the reference's models/team29_FreqFusion/io.py: same entry point
 locations and formats, same image I/O, same "whole image, else 128/32 overlap tiles on OOM" policy --
 but `model(lr)` runs on hand-written HIP kernels (image-super-resolution-2_amd/) instead of ATen.
 The device must be an MI355X: a CPU `device` raises (there is no fallback path).
+
+What this build adds around the same contract:
+  * one process per GPU: when WORLD_SIZE > 1 (torch.distributed.run, or isr2_amd.run_sharded) rank r takes a contiguous
+    shard of the sorted image list (as the reference's eval.py:166-170 shards files over workers), the frozen weights are
+    built by rank 0 and sent in ONE RCCL broadcast, every rank writes its own PNGs -- no per-image collective;
+  * PNG decode and encode run on host threads beside the GPU (pinned uint8 staging, only uint8 crosses PCIe); the
+    compute stays on the calling thread, results and file names are exactly those of the serial loop;
+  * tiles (and repeated whole-image shapes) replay one captured HIP graph instead of re-launching ~1700 kernels.
 """
 from __future__ import annotations
 
 import glob
 import os
+import queue
 import sys
+import threading
+import time
 import warnings
 from collections import OrderedDict
 
@@ -24,7 +35,9 @@ if _PROJECT_ROOT not in sys.path:
     sys.path.insert(0, _PROJECT_ROOT)
 
 from isr2_amd import ops  # noqa: E402
+from isr2_amd.lib import FFError  # noqa: E402
 from isr2_amd.model import FreqFusionHIP  # noqa: E402
+from isr2_amd.parallel import shard_list, broadcast_state_dict  # noqa: E402
 from isr2_amd.weights import synth_state_dict, param_spec, HAT_PREFIX, DAT_PREFIX, NAF_PREFIX  # noqa: E402
 
 # reference io.py:40-58 -- the flags the shipped checkpoint was trained with; this build implements exactly
@@ -70,31 +83,47 @@ def _tile_positions(n: int, tile: int, step: int):
     return ps
 
 
+_RAMPS = {}
+
+
+def _ramp_table(st: int, blend: int, device) -> torch.Tensor:
+    """The four edge-weight vectors a tile can have along one axis, [4, st] on the device, built ONCE per (tile, blend):
+    row (has_prev + 2 * has_next) = ones, with a linear 0..1 ramp over the first `blend` samples when a tile precedes and
+    a 1..0 ramp over the last `blend` when one follows (reference io.py:104-117)."""
+    key = (st, blend, str(device))
+    tab = _RAMPS.get(key)
+    if tab is None:
+        w = np.ones((4, st), dtype=np.float32)
+        if blend > 0:
+            ramp = np.linspace(0.0, 1.0, blend, dtype=np.float32)
+            for v in range(4):
+                if v & 1:
+                    w[v, :blend] = ramp
+                if v & 2:
+                    w[v, -blend:] = 1 - ramp
+        tab = _RAMPS[key] = torch.from_numpy(w).to(device)
+    return tab
+
+
 def _tiled_forward(model, lr_img, tile_size=64, overlap=8, scale=4, device="cuda"):
-    """Overlap tiles with linear-ramp blending on interior edges (reference io.py:82-121)."""
+    """Overlap tiles with linear-ramp blending on interior edges (reference io.py:82-121).  Tiles of one shape replay one
+    captured HIP graph when the model offers it (`model.graphed`); the blend weights live on the device."""
     _, _, h, w = lr_img.shape
     acc = torch.zeros(1, 3, h * scale, w * scale, device=device)
     wsum = torch.zeros(1, 1, h * scale, w * scale, device=device)
     step = tile_size - overlap
     st = tile_size * scale
     blend = min(overlap * scale, st // 4)
-    ramp = np.linspace(0.0, 1.0, blend, dtype=np.float32) if blend > 0 else None
+    ramps = _ramp_table(st, blend, device)
+    run = getattr(model, "graphed", None) if os.environ.get("FF_TILE_GRAPH", "1") != "0" else None
     for y in _tile_positions(h, tile_size, step):
         for x in _tile_positions(w, tile_size, step):
-            sr_tile = model(lr_img[:, :, y:y + tile_size, x:x + tile_size].contiguous())
-            wy, wx = np.ones(st, dtype=np.float32), np.ones(st, dtype=np.float32)
-            if blend > 0:
-                if y > 0:
-                    wy[:blend] = ramp
-                if y + tile_size < h:
-                    wy[-blend:] = 1 - ramp
-                if x > 0:
-                    wx[:blend] = ramp
-                if x + tile_size < w:
-                    wx[-blend:] = 1 - ramp
+            lr_tile = lr_img[:, :, y:y + tile_size, x:x + tile_size].contiguous()
+            sr_tile = run(lr_tile) if run is not None else model(lr_tile)
             th, tw = sr_tile.shape[-2:]
-            ops.tile_accum(sr_tile, torch.from_numpy(wy[:th].copy()).to(device), torch.from_numpy(wx[:tw].copy()).to(device),
-                           acc, wsum, y * scale, x * scale)
+            wy = ramps[(1 if y > 0 else 0) + (2 if y + tile_size < h else 0)]
+            wx = ramps[(1 if x > 0 else 0) + (2 if x + tile_size < w else 0)]
+            ops.tile_accum(sr_tile, wy[:th], wx[:tw], acc, wsum, y * scale, x * scale)
     ops.tile_normalize(acc, wsum)
     return acc
 
@@ -108,10 +137,17 @@ def _extract_state_dict(ckpt):
     return OrderedDict((k.replace("module.", ""), v) for k, v in ckpt.items())
 
 
+def _allow_synth() -> bool:
+    return os.environ.get("FF_ALLOW_SYNTH", "0") == "1"
+
+
 def _build_state_dict(model_dir: str, pretrained_dir: str, verbose: bool = True):
     """Assemble the reference-keyed state dict: seeded synthetic values first (the stand-in for the
-    reference's random init when a file is missing), then every tensor found in the checkpoints whose
-    name and shape match (reference io.py:164-177, expert_loader.py:146-157, nafnet/__init__.py:84-115)."""
+    reference's random init when an EXPERT file is missing -- expert_loader.py:363-368 warns and keeps the random init),
+    then every tensor found in the checkpoints whose name and shape match (reference io.py:164-177,
+    expert_loader.py:146-157, nafnet/__init__.py:84-115).
+    The FUSION checkpoint is mandatory, as in the reference (io.py:164 `torch.load` raises on a missing file): a missing or
+    empty one raises unless FF_ALLOW_SYNTH=1 opts into seeded synthetic fusion weights (tests / benchmarks)."""
     sd = synth_state_dict(SYNTH_SEED)
     shapes = {n: tuple(s) for n, s, _ in param_spec()}
     for name, (sub, fname, prefix) in EXPERT_FILES.items():
@@ -142,43 +178,235 @@ def _build_state_dict(model_dir: str, pretrained_dir: str, verbose: bool = True)
                 n += 1
         if verbose:
             print(f"[team29_FreqFusion] Loaded {n} fusion weight tensors from checkpoint")
+        if n == 0 and not _allow_synth():
+            raise RuntimeError(f"[team29_FreqFusion] {model_dir}: no tensor of the checkpoint matches the model "
+                               "(expected a dict with 'model_state_dict'); refusing to run on synthetic fusion weights")
+    elif _allow_synth():
+        warnings.warn(f"[team29_FreqFusion] fusion checkpoint not found: {model_dir} -- FF_ALLOW_SYNTH=1: seeded synthetic weights")
     else:
-        warnings.warn(f"[team29_FreqFusion] fusion checkpoint not found: {model_dir} -- using seeded synthetic weights")
+        raise FileNotFoundError(f"[team29_FreqFusion] fusion checkpoint not found: {model_dir} "
+                                "(set FF_ALLOW_SYNTH=1 to run on seeded synthetic fusion weights)")
     return sd
 
 
-def _build_and_load(model_dir: str, device):
+def _dist_env():
+    """(rank, world, local_rank) of a torch.distributed.run / run_sharded launch; (0, 1, 0) otherwise."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, 0
+    rank = int(os.environ.get("RANK", "0"))
+    return rank, world, int(os.environ.get("LOCAL_RANK", str(rank)))
+
+
+def _ensure_process_group(rank: int, world: int, device):
+    """Join the job's process group (RCCL = backend 'nccl' on ROCm; FF_DIST_BACKEND=gloo for CPU-side rehearsals)."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return False
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29529")
+    backend = os.environ.get("FF_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return True
+
+
+def _build_and_load(model_dir: str, device, rank: int = 0, world: int = 1):
     pretrained_dir = os.environ.get("FREQFUSION_PRETRAINED", os.path.join(_PROJECT_ROOT, "pretrained"))
-    return FreqFusionHIP(_build_state_dict(model_dir, pretrained_dir), device)
+    if world <= 1:
+        return FreqFusionHIP(_build_state_dict(model_dir, pretrained_dir), device)
+    # N > 1: rank 0 reads the checkpoints, everyone receives the 690 MB of frozen weights in ONE broadcast over xGMI
+    src = _build_state_dict(model_dir, pretrained_dir, verbose=True) if rank == 0 else None
+    sd = broadcast_state_dict(src, param_spec(), rank, world, torch.device(device))
+    return FreqFusionHIP(sd, device)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Host image pipeline (SURVEY 8f rank 3): decode and encode beside the GPU
+class _HostPipeline:
+    """Reader thread: PNG -> uint8 HWC in a pinned staging slot.  Writer threads: pinned uint8 HWC -> PNG.
+    The calling thread owns every GPU call (H2D copy, kernels, D2H copy); a slot is reused only after the event that marks
+    its last copy has completed.  Exceptions raised on a worker thread are re-raised on the calling thread."""
+
+    def __init__(self, paths, out_dir, device, n_slots: int = 3, n_writers: int = 2):
+        self.paths, self.out_dir, self.device = list(paths), out_dir, device
+        self.err = None
+        self.in_free, self.in_ready = queue.Queue(), queue.Queue()
+        self.out_free, self.out_ready = queue.Queue(), queue.Queue()
+        for _ in range(n_slots):
+            self.in_free.put({"buf": None, "ev": None})
+            self.out_free.put({"buf": None})
+        self.t_decode = self.t_encode = 0.0
+        self.reader = threading.Thread(target=self._read_loop, name="ff-png-reader", daemon=True)
+        self.writers = [threading.Thread(target=self._write_loop, name=f"ff-png-writer{i}", daemon=True) for i in range(n_writers)]
+        self.reader.start()
+        for t in self.writers:
+            t.start()
+
+    @staticmethod
+    def _pinned(slot, nbytes: int):
+        if slot["buf"] is None or slot["buf"].numel() < nbytes:
+            slot["buf"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+        return slot["buf"]
+
+    def _read_loop(self):
+        try:
+            for p in self.paths:
+                slot = self.in_free.get()
+                if slot is None:
+                    return
+                if slot["ev"] is not None:
+                    slot["ev"].synchronize()                     # the previous H2D copy out of this slot has finished
+                t0 = time.perf_counter()
+                arr = np.asarray(Image.open(p).convert("RGB"), dtype=np.uint8)
+                h, w, _ = arr.shape
+                buf = self._pinned(slot, arr.size)
+                buf[:arr.size].view(h, w, 3).numpy()[...] = arr
+                self.t_decode += time.perf_counter() - t0
+                self.in_ready.put((slot, p, h, w))
+        except BaseException as e:                               # noqa: BLE001 -- handed to the calling thread
+            self.err = e
+        finally:
+            self.in_ready.put(None)
+
+    def _write_loop(self):
+        try:
+            while True:
+                item = self.out_ready.get()
+                if item is None:
+                    return
+                slot, ev, name, h, w = item
+                ev.synchronize()                                 # the D2H copy into this slot has finished
+                t0 = time.perf_counter()
+                arr = slot["buf"][:h * w * 3].view(h, w, 3).numpy()
+                Image.fromarray(arr).save(os.path.join(self.out_dir, name), format="PNG")
+                self.t_encode += time.perf_counter() - t0
+                self.out_free.put(slot)
+        except BaseException as e:                               # noqa: BLE001
+            self.err = e
+            self.out_free.put({"buf": None})                     # keep the producer from blocking forever
+
+    def _check(self):
+        if self.err is not None:
+            raise self.err
+
+    def __iter__(self):
+        """Yields (path, lr [1,3,H,W] fp32 on the device) in list order."""
+        while True:
+            item = self.in_ready.get()
+            self._check()
+            if item is None:
+                return
+            slot, p, h, w = item
+            dev_u8 = slot["buf"][:h * w * 3].view(h, w, 3).to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            slot["ev"] = ev
+            self.in_free.put(slot)
+            yield p, ops.u8_to_f32_image(dev_u8)
+
+    def save(self, sr: torch.Tensor, name: str):
+        """Queue `sr` [1,3,H,W] (device) for PNG encoding: converted to uint8 HWC on the device, copied to a pinned slot."""
+        self._check()
+        u8 = ops.f32_to_u8_image(sr)
+        h, w, _ = u8.shape
+        slot = self.out_free.get()
+        self._check()
+        self._pinned(slot, u8.numel())[:u8.numel()].view(h, w, 3).copy_(u8, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        u8.record_stream(torch.cuda.current_stream())
+        self.out_ready.put((slot, ev, name, h, w))
+
+    def close(self):
+        for _ in self.writers:
+            self.out_ready.put(None)
+        for t in self.writers:
+            t.join()
+        self.in_free.put(None)
+        self.reader.join(timeout=5)
+        self._check()
+
+
+def _forward_image(model, lr_img, img_name, device, seen_shapes):
+    """Whole image, else 128/32 overlap tiles when the whole image does not fit (reference io.py:219-228).  Besides the
+    allocator's 'out of memory', a kernel's own size limit (FFError, e.g. the direct-DFT row length) selects the tiles."""
+    shape = tuple(lr_img.shape)
+    try:
+        if seen_shapes is not None and hasattr(model, "graphed") and seen_shapes.get(shape, 0) >= 1:
+            sr = model.graphed(lr_img)                          # a shape that repeats replays its captured graph
+        else:
+            sr = model(lr_img)
+        if seen_shapes is not None:
+            seen_shapes[shape] = seen_shapes.get(shape, 0) + 1
+        return sr
+    except RuntimeError as e:                                    # torch.cuda.OutOfMemoryError and FFError are RuntimeErrors
+        msg = str(e).lower()
+        if "out of memory" in msg or (isinstance(e, FFError) and ("too large" in msg or "exceeds" in msg or "limit" in msg)):
+            if torch.device(device).type == "cuda":
+                torch.cuda.empty_cache()
+            print(f"  OOM on {img_name}, switching to tiled inference (128px)...")
+            return _tiled_forward(model, lr_img, tile_size=128, overlap=32, scale=4, device=device)
+        raise
 
 
 @torch.no_grad()
 def main(model_dir: str, input_path: str, output_path: str, device=None):
     """NTIRE2026 official interface (reference io.py:188-234)."""
+    rank, world, local_rank = _dist_env()
     if device is None:
         device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     device = torch.device(device)
-    print(f"[team29_FreqFusion] Device: {device}")
-    model = _build_and_load(model_dir, device)
+    if world > 1 and device.type == "cuda":
+        device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+        torch.cuda.set_device(device)
+    tag = f"[team29_FreqFusion r{rank}/{world}]" if world > 1 else "[team29_FreqFusion]"
+    print(f"{tag} Device: {device}")
+    own_pg = _ensure_process_group(rank, world, device) if world > 1 else False
+    model = _build_and_load(model_dir, device, rank, world)
 
     input_imgs = sorted(glob.glob(os.path.join(input_path, "*.[pP][nN][gG]")))
     if not input_imgs:
         input_imgs = sorted(glob.glob(os.path.join(input_path, "*.[jJ][pP]*[gG]")))
-    print(f"[team29_FreqFusion] Found {len(input_imgs)} images in {input_path}")
+    print(f"{tag} Found {len(input_imgs)} images in {input_path}")
     os.makedirs(output_path, exist_ok=True)
+    mine = shard_list(input_imgs, rank, world)                  # contiguous shard of the sorted list; whole images per rank
+    if world > 1:
+        print(f"{tag} this rank processes {len(mine)} of them")
 
-    for img_path in input_imgs:
-        img_name = os.path.basename(img_path)
-        lr_img = _load_image(img_path, device)
+    t0 = time.perf_counter()
+    if os.environ.get("FF_IO_THREADS", "1") == "0" or device.type != "cuda":   # the reference's serial loop, kept for A/B timing
+        for img_path in mine:
+            img_name = os.path.basename(img_path)
+            lr_img = _load_image(img_path, device)
+            sr_img = _forward_image(model, lr_img, img_name, device, None)
+            _save_image(sr_img, os.path.join(output_path, img_name))
+            del sr_img, lr_img
+    else:
+        seen = {}
+        pipe = _HostPipeline(mine, output_path, device)
         try:
-            sr_img = model(lr_img)
-        except RuntimeError as e:                      # torch.cuda.OutOfMemoryError is a RuntimeError
-            if "out of memory" in str(e).lower():
-                torch.cuda.empty_cache()
-                print(f"  OOM on {img_name}, switching to tiled inference (128px)...")
-                sr_img = _tiled_forward(model, lr_img, tile_size=128, overlap=32, scale=4, device=device)
-            else:
-                raise
-        _save_image(sr_img, os.path.join(output_path, img_name))
-        del sr_img, lr_img
-    print(f"[team29_FreqFusion] Done. {len(input_imgs)} images saved to {output_path}")
+            for img_path, lr_img in pipe:
+                img_name = os.path.basename(img_path)
+                sr_img = _forward_image(model, lr_img, img_name, device, seen)
+                pipe.save(sr_img, img_name)
+                del sr_img, lr_img
+        finally:
+            pipe.close()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        stats = torch.tensor([float(len(mine)), dt], device=device, dtype=torch.float64)
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)                         # end-of-run bookkeeping only (counts and wall time)
+        if rank == 0:
+            tot = int(sum(float(g[0]) for g in gathered))
+            print(f"{tag} all ranks: {tot} images, slowest rank {max(float(g[1]) for g in gathered):.2f} s")
+            assert tot == len(input_imgs), (tot, len(input_imgs))
+        if own_pg:
+            dist.destroy_process_group()
+    print(f"{tag} Done. {len(mine)} images saved to {output_path}")

@@ -1,0 +1,137 @@
+"""Goldens at the BENCHMARKED sizes, generated from the IMPORTED reference (build container only).
+
+    python tests/golden/make_golden_big.py tile256     # one 256x256 LR tile (bench.py's rank-0 tile), ~3 min
+    python tests/golden/make_golden_big.py config3     # BASELINE config 3: reference io._tiled_forward(model, lr, 256, 32)
+                                                       #   on one 510x339 1/f image (6 tiles), ~15-20 min
+    python tests/golden/make_golden_big.py b2          # a B=2 48x48 batch through the reference (batched-forward parity)
+
+A 1024x1024x3 fp32 output is 12.6 MB, so only data a test can check cheaply is stored:
+  * for every tap (same names as make_golden.py): 4096 seeded samples + (mean, mean|x|, L2) over the whole tensor,
+  * for `final` and each expert output: 65536 seeded samples and four 64x64 HR crops (three fixed + the worst-case
+    corner), and for config 3 crops that straddle the blend seams,
+  * the oracle-vs-reference deviation at this size (the oracle's pinning at 256x256).
+Only these arrays are committed; the reference's code never leaves this container.
+"""
+import os
+import sys
+import json
+import time
+import contextlib
+import io as _io
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+from _ref_import import build_reference_model, install_shims  # noqa: E402
+from make_golden import make_input, summarize, load_synth_into_reference, reference_taps, sample_idx  # noqa: E402
+from oracle import freqfusion_oracle as O  # noqa: E402
+
+NBIG = 65536
+CROP = 64
+
+
+def big_samples(name, t):
+    f = t.detach().float().reshape(-1).numpy()
+    import hashlib
+    s = int.from_bytes(hashlib.sha256(("big/" + name).encode()).digest()[:4], "little")
+    idx = np.random.default_rng(s).integers(0, f.size, size=NBIG)
+    return idx.astype(np.int64), f[idx].astype(np.float32)
+
+
+def crops_of(t, corners):
+    return np.stack([t[0, :, y:y + CROP, x:x + CROP].numpy() for (y, x) in corners]).astype(np.float32)
+
+
+def tile256(model, sd):
+    lr = make_input("natural", 256, 256, 100)          # == bench.make_tile(100): the tile bench.py times on rank 0
+    t0 = time.time()
+    ref = reference_taps(model, lr)
+    t_ref = time.time() - t0
+    print(f"reference forward+taps at 256x256: {t_ref:.1f} s", flush=True)
+    blob = {"lr": lr.numpy()}
+    corners = [(0, 0), (480, 480), (960, 960), (100, 900)]
+    blob["crop_corners"] = np.array(corners, dtype=np.int64)
+    for k, v in ref.items():
+        s = summarize(k, v)
+        for kk, vv in s.items():
+            blob[f"tap/{k}/{kk}"] = vv
+    for k in ("final", "expert.hat", "expert.dat", "expert.nafnet"):
+        i, v = big_samples(k, ref[k])
+        blob[f"big/{k}/idx"], blob[f"big/{k}/val"] = i, v
+        blob[f"crop/{k}"] = crops_of(ref[k], corners)
+    np.savez_compressed(os.path.join(HERE, "t256_nat.npz"), **blob)
+    print("wrote t256_nat.npz", flush=True)
+    # pin the oracle at this size
+    t0 = time.time()
+    otaps = {}
+    out = O.forward(sd, lr, otaps)
+    otaps["final"] = out
+    t_or = time.time() - t0
+    dev = {k: float((otaps[k] - v).abs().max()) for k, v in ref.items() if k in otaps}
+    flips = float(((otaps["fusion.gates"] - ref["fusion.gates"]).abs() > 1e-3).float().mean()) if "fusion.gates" in otaps else None
+    rep = {"max_abs_dev": dev, "psnr_final": O.psnr(out, ref["final"]), "gates_frac_gt_1e-3": flips,
+           "reference_seconds_8_threads": t_ref, "oracle_seconds_8_threads": t_or}
+    print("oracle-vs-reference at 256x256:", sorted(dev.items(), key=lambda kv: -kv[1])[:6], "PSNR", rep["psnr_final"], flush=True)
+    return rep
+
+
+def config3(model, sd):
+    install_shims()
+    with contextlib.redirect_stdout(_io.StringIO()):
+        import importlib
+        plug = importlib.import_module("models.team29_FreqFusion.io")
+    h, w = 339, 510
+    lr = make_input("natural", h, w, 31)
+    _orig = torch.cuda.empty_cache
+    torch.cuda.empty_cache = lambda: None
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            out = plug._tiled_forward(model, lr, tile_size=256, overlap=32, scale=4, device="cpu")
+    finally:
+        torch.cuda.empty_cache = _orig
+    dt = time.time() - t0
+    print(f"reference _tiled_forward(510x339, 256, 32): {dt:.1f} s", flush=True)
+    # tile origins: x in {0,224,254}, y in {0,83}; seams (HR) around x=896..1024, 1016..1152, y=332..1024
+    corners = [(0, 0), (300, 880), (332, 1000), (600, 1100), (1292, 1976), (1000, 1500), (340, 20), (980, 940)]
+    blob = {"lr": lr.numpy(), "crop_corners": np.array(corners, dtype=np.int64), "crops": crops_of(out, corners)}
+    i, v = big_samples("config3", out)
+    blob["big/idx"], blob["big/val"] = i, v
+    f = out.reshape(-1).numpy().astype(np.float64)
+    blob["stats"] = np.array([f.mean(), np.abs(f).mean(), np.sqrt((f ** 2).sum())])
+    blob["shape"] = np.array(out.shape, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "config3_510x339.npz"), **blob)
+    print("wrote config3_510x339.npz", flush=True)
+    return {"reference_seconds_8_threads": dt, "shape": list(out.shape)}
+
+
+def b2(model, sd):
+    lr = torch.cat([make_input("natural", 48, 48, 41), make_input("uniform", 48, 48, 42)], 0)
+    with torch.no_grad():
+        out = model(lr)
+        one = torch.cat([model(lr[0:1]), model(lr[1:2])], 0)
+    blob = {"lr": lr.numpy(), "out": out.numpy().astype(np.float32)}
+    np.savez_compressed(os.path.join(HERE, "b2_48.npz"), **blob)
+    return {"ref_batched_vs_single_max_abs": float((out - one).abs().max())}
+
+
+def main():
+    what = sys.argv[1:] or ["tile256"]
+    torch.manual_seed(0)
+    torch.set_num_threads(int(os.environ.get("FF_THREADS", "8")))
+    model, ens = build_reference_model()
+    sd = load_synth_into_reference(model)
+    rp = os.path.join(HERE, "big_pinning_report.json")
+    report = json.load(open(rp)) if os.path.exists(rp) else {}
+    for wname in what:
+        report[wname] = {"tile256": tile256, "config3": config3, "b2": b2}[wname](model, sd)
+        json.dump(report, open(rp, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,7 @@
 """End-to-end GPU parity: the HIP path against (a) the committed reference goldens and (b) the CPU oracle,
 stage by stage.  Bar (BASELINE north_star): within 0.01 dB PSNR of the reference in fp32; we additionally
-require max|d| <= 5e-4 on every tap and PSNR(hip, reference) >= 80 dB."""
+require every intermediate tap within 2e-4 (relative to max(1,|ref|)) and PSNR(hip, reference) >= 110 dB
+(measured: 4.3e-5 / 123.8 dB for bf16x3, 3e-6 / 143 dB for f32)."""
 import os
 
 import numpy as np
@@ -13,7 +14,8 @@ TAP_TOL = 5e-4
 
 
 # per contraction mode: (max tap deviation relative to max(1,|ref|), min PSNR vs the reference in dB)
-BARS = {"f32": (5e-4, 100.0), "bf16x3": (2e-3, 80.0)}
+BARS = {"f32": (5e-5, 125.0), "bf16x3": (2e-4, 110.0)}
+GATE_FLIP_FRAC = 1e-3      # dynamic-selection gates have a hard threshold: at most 0.1 % of pixels may differ by > 1e-3
 
 
 @pytest.fixture(scope="module", params=["f32", "bf16x3"])
@@ -62,10 +64,16 @@ def test_against_reference_goldens(model, case):
             t = t.reshape(shape)
         ref = torch.from_numpy(g[f"tap/{n}/val"])
         got = t.reshape(-1)[torch.from_numpy(g[f"tap/{n}/idx"])]
+        if n == "fusion.gates":
+            # hard threshold (fusion_network.py:232-234: gates >= 0.99 max): single pixels may legitimately land on the other
+            # side, so the bar is on the FRACTION of pixels that differ, not on the worst one
+            flips = ((got - ref).abs() > 1e-3).float().mean().item()
+            print(case, model.mode, "fusion.gates: fraction differing by > 1e-3 =", flips)
+            assert flips <= GATE_FLIP_FRAC, flips
+            continue
         worst[n] = (got - ref).abs().max().item() / max(1.0, float(ref.abs().max()))
     tol, min_psnr = BARS[model.mode]
-    # the dynamic-selection gate has a hard threshold (fusion_network.py:232-234): a few pixels may flip
-    bad = {k: v for k, v in worst.items() if not v < tol and k != "fusion.gates"}
+    bad = {k: v for k, v in worst.items() if not v < tol}
     print(case, model.mode, "worst taps:", sorted(worst.items(), key=lambda kv: -kv[1])[:8])
     assert not bad, bad
     psnr = O.psnr(out, torch.from_numpy(g["full/final"]))
@@ -85,5 +93,5 @@ def test_against_oracle_odd_size(model, synth_sd):
     out = model(lr.cuda()).cpu()
     tol, min_psnr = BARS[model.mode]
     print("odd size", model.mode, "max|d| =", (out - ref).abs().max().item(), "PSNR =", O.psnr(out, ref))
-    assert (out - ref).abs().max().item() < 10 * tol
+    assert (out - ref).abs().max().item() < 5 * tol
     assert O.psnr(out, ref) >= min_psnr

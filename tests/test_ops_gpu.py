@@ -512,3 +512,106 @@ def test_fuse_blend(dev):
     f0 = hier * 0.7 + 0.3 * sum(e * g[..., i:i + 1] for i, e in enumerate(ex))
     dyn = sum(e * gt[..., i:i + 1] for i, e in enumerate(ex)) / (gt.sum(-1, keepdim=True) + 1e-8)
     close(out, f0 * (1 - 0.3 * df) + dyn * (0.3 * df), 2e-6, "fuse blend")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Bench-size shapes (one 256x256 LR tile = 65 536 tokens): the tile variants that only large M selects.
+@pytest.mark.parametrize("M,K,N", [(65536, 360, 180),     # DAT fc2: cfg 4 (256x192, 8 waves) because N <= 192
+                                   (65536, 320, 360),     # cfg 4 through r192 = 168 > 128 and K >= 320
+                                   (65536, 384, 540),     # cfg 4 through r192 = 156
+                                   (65536, 180, 540),     # wide N at K = 180: 128x128 tiles
+                                   (16384 + 37, 720, 180)])   # ragged M just above the cfg-4 threshold
+def test_linear_at_bench_size(dev, gemm_mode, M, K, N):
+    """ops.linear at M = 65 536 against torch fp32 (the 256x192 tile of conv_gemm_bf16.hip needs M >= 16384
+    and was never compared with anything)."""
+    from isr2_amd import ops
+    x = rnd(M, K, dev=dev, seed=200)
+    w = rnd(N, K, dev=dev, seed=201, scale=1.0 / math.sqrt(K))
+    b = rnd(N, dev=dev, seed=202, scale=0.1)
+    res = rnd(M, N, dev=dev, seed=203)
+    ref = res + F.gelu(F.linear(x, w, b))
+    close(ops.linear(x, w, b, act="gelu", res=res), ref, GEMM_TOL[gemm_mode], "linear @ bench size")
+
+
+@pytest.mark.parametrize("halo", [True, False])
+@pytest.mark.parametrize("Cin,Cout,hw", [(180, 180, 256), (180, 60, 256), (64, 64, 512), (76, 64, 256)])
+def test_conv3x3_at_bench_size(dev, gemm_mode, halo, Cin, Cout, hw):
+    """3x3 convolutions on the bench tile's grids (256x256 tokens for HAT/DAT, 512x512 for the fusion stack): the LDS-resident
+    kernel with pool partials over 256+ workgroups, and the implicit GEMM's large-M tile (halo off)."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_conv
+    x = rnd(1, Cin, hw, hw, dev=dev, seed=210)
+    w = rnd(Cout, Cin, 3, 3, dev=dev, seed=211, scale=1.0 / math.sqrt(9 * Cin))
+    b = rnd(Cout, dev=dev, seed=212, scale=0.1)
+    ref = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1)
+    ops.set_halo(halo)
+    try:
+        out, pooled = ops.conv2d(x.permute(0, 2, 3, 1).contiguous(), pack_conv(w), b, ksize=(3, 3), pad=(1, 1), want_pool=True)
+    finally:
+        ops.set_halo(True)
+    close(out, ref, GEMM_TOL[gemm_mode], "conv3x3 @ bench size")
+    close(pooled, ref.mean(dim=(1, 2)), 2e-5, "global average pool from the conv epilogue @ bench size")
+
+
+def test_chan_attn_weights_at_bench_size(dev):
+    """DAT channel attention statistics over 65 536 tokens (the split-K reduction that only this size exercises)."""
+    from isr2_amd import ops
+    N, C, heads, d = 65536, 180, 6, 30
+    qkv = torch.empty(N, 544, device=dev)[:, :540]                  # padded pitch, as token_linear produces it
+    qkv.copy_(rnd(N, 3 * C, dev=dev, seed=220))
+    temp = (rnd(heads, dev=dev, seed=221) * 0.2 + 1.0).contiguous()
+    wbd = ops.chan_attn_weights(qkv, 0, C, temp)
+    q = qkv[:, :C].double().reshape(N, heads, d).permute(1, 2, 0)
+    k = qkv[:, C:2 * C].double().reshape(N, heads, d).permute(1, 2, 0)
+    a = torch.softmax((F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)) * temp.double()[:, None, None], dim=-1)
+    close(wbd, torch.block_diag(*[a[h] for h in range(heads)]).float(), 1e-5, "chan attn @ 65536 tokens")
+
+
+@pytest.mark.parametrize("C,H,W", [(64, 1024, 1024), (128, 512, 512)])
+def test_naf_dwconv_gate_pool_at_bench_size(dev, C, H, W):
+    """NAFNet dw3x3 + SimpleGate + pool with 1024 row-strip partials (the HR levels of the bench tile)."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_dw
+    t = rnd(1, 2 * C, H, W, dev=dev, seed=230)
+    w = rnd(2 * C, 1, 3, 3, dev=dev, seed=231, scale=0.3)
+    b = rnd(2 * C, dev=dev, seed=232, scale=0.1)
+    y = F.conv2d(t, w, b, padding=1, groups=2 * C)
+    ref = (y[:, :C] * y[:, C:]).permute(0, 2, 3, 1)
+    out, pooled = ops.dwconv3_gate_pool(t.permute(0, 2, 3, 1).contiguous(), pack_dw(w), b)
+    close(out, ref, 1e-5, "dw3x3 gate")
+    close(pooled, ref.double().mean(dim=(1, 2)).float(), 1e-5, "dw3x3 gate pool")
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (339, 510)])
+def test_freq_bands_at_bench_size(dev, H, W):
+    """256-point direct DFT, the 64x64 -> 256x129 mask resample, DCT/DWT at the bench tile (and config 3's image size)."""
+    from isr2_amd.fusion import FreqBands
+    from isr2_amd.weights import synth_state_dict
+    from oracle import freqfusion_oracle as O
+    sd = synth_state_dict(1234, parts=("fusion",))
+    lr = torch.from_numpy(np.random.default_rng(5).random((1, 3, H, W), dtype=np.float32))
+    ref = torch.cat(O.freq_decompose(sd, lr), dim=1).permute(0, 2, 3, 1)
+    out = FreqBands({k: v.to(dev) for k, v in sd.items()}, dev)(lr.to(dev))
+    for i in range(9):
+        close(out[..., 3 * i:3 * i + 3].cpu(), ref[..., 3 * i:3 * i + 3], 2e-5, f"band {i}")
+
+
+def test_dynamic_gates_matches_reference_formula(dev):
+    """ff_dynamic_gates against the formula of DynamicExpertSelector.forward (fusion_network.py:222-234): threshold
+    0.7 - 0.4 d, sigmoid(10 (g - th)), max-gate floor 0.9 on every gate within 1 % of the per-pixel maximum."""
+    from isr2_amd import ops
+    P = 40000
+    g = torch.sigmoid(rnd(1, 200, 200, 3, dev=dev, seed=240) * 2.0)
+    d = torch.sigmoid(rnd(1, 200, 200, 1, dev=dev, seed=241))
+    g[0, 0, :8] = torch.tensor([0.5, 0.5, 0.5], device=dev)               # exact three-way ties
+    g[0, 1, :8, 1] = g[0, 1, :8, 0]                                        # exact two-way ties
+    out = ops.dynamic_gates(g.contiguous(), d.contiguous())
+    th = 0.7 - 0.4 * d
+    s = torch.sigmoid(10.0 * (g - th))
+    mx = s.max(dim=-1, keepdim=True).values
+    ref = torch.maximum(s, (s >= mx * 0.99).float() * 0.9)
+    dlt = (out - ref).abs()
+    # a gate sitting within an ulp of 0.99 * max may fall on either side of the hard comparison: bound the fraction of such pixels
+    assert (dlt > 1e-5).float().mean().item() <= 1e-4, (dlt > 1e-5).float().mean().item()
+    assert (out.max(dim=-1).values >= 0.9 - 1e-6).all(), "at least one expert must be selected per pixel"
+    assert out.numel() == 3 * P

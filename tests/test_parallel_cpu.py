@@ -66,3 +66,80 @@ def test_two_rank_gloo_broadcast_and_sharding():
     assert [r[0] for r in res] == [0, 1]
     assert all(r[1] for r in res), "broadcast state dict differs from rank 0's"
     assert all(r[2] == float(sum(range(601))) for r in res)
+
+
+# ---- image-sharded plugin driver (BASELINE config 4), two gloo ranks on CPU ---------------------------------------------
+def _plugin_worker(rank, world, port, src, dst, logdir):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port), "FF_DIST_BACKEND": "gloo", "FF_IO_THREADS": "0"})
+    import models.team29_FreqFusion.io as plug
+
+    class StandIn:                                   # the HIP model needs a GPU; sharding / naming / collectives do not
+        def __call__(self, x):
+            return torch.nn.functional.interpolate(x, scale_factor=4, mode="nearest")
+
+    seen = []
+    orig_load = plug._load_image
+    plug._build_and_load = lambda model_dir, device, rank=0, world=1: StandIn()
+    plug._load_image = lambda path, device=None: (seen.append(os.path.basename(path)), orig_load(path, None))[1]
+    plug.main(model_dir="unused.pth", input_path=src, output_path=dst, device=torch.device("cpu"))
+    with open(os.path.join(logdir, f"rank{rank}.txt"), "w") as f:
+        f.write("\n".join(seen))
+
+
+def test_two_rank_plugin_shards_every_image_exactly_once(tmp_path):
+    """main() under WORLD_SIZE=2: the sorted file list is cut into contiguous shards (reference eval.py:166-170), every image is
+    read by exactly one rank and written exactly once, names are preserved, and the closing all_gather agrees on the total."""
+    import numpy as np
+    from PIL import Image
+    src, dst, logs = tmp_path / "in", tmp_path / "out", tmp_path / "logs"
+    for d in (src, dst, logs):
+        d.mkdir()
+    names = [f"img_{i:03d}.png" for i in range(7)]
+    rng = np.random.default_rng(0)
+    for n in names:
+        Image.fromarray(rng.integers(0, 256, size=(6, 5, 3), dtype=np.uint8)).save(src / n)
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_plugin_worker, args=(r, 2, port, str(src), str(dst), str(logs))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    per_rank = [open(logs / f"rank{r}.txt").read().split() for r in range(2)]
+    assert per_rank[0] == names[:4] and per_rank[1] == names[4:]              # contiguous, first rank takes the extra one
+    assert sorted(os.listdir(dst)) == names
+    for n in names:                                                            # nearest x4 of the input: content is the right image's
+        a, b = np.array(Image.open(src / n)), np.array(Image.open(dst / n))
+        assert b.shape == (24, 20, 3) and np.array_equal(b[::4, ::4], a)
+
+
+def test_spawn_ranks_sets_rank_environment_and_reports_failure(tmp_path):
+    """parallel.spawn_ranks (what `bench.py --gpus N` and run_sharded use to start themselves): one fresh child per rank with
+    the torch.distributed.run environment; a failing rank makes the job fail."""
+    import sys
+    from isr2_amd.parallel import spawn_ranks
+    code = ("import os,sys; open(os.path.join(sys.argv[1], 'r' + os.environ['RANK']), 'w').write("
+            "os.environ['WORLD_SIZE'] + ' ' + os.environ['LOCAL_RANK'] + ' ' + os.environ['MASTER_ADDR']); "
+            "sys.exit(3 if os.environ['RANK'] == sys.argv[2] else 0)")
+    assert spawn_ranks([sys.executable, "-c", code, str(tmp_path), "-1"], 3) == 0
+    assert sorted(os.listdir(tmp_path)) == ["r0", "r1", "r2"]
+    assert open(tmp_path / "r2").read() == "3 2 127.0.0.1"
+    assert spawn_ranks([sys.executable, "-c", code, str(tmp_path), "1"], 2) == 3
+
+
+def test_fusion_checkpoint_is_mandatory(tmp_path, monkeypatch):
+    """a missing fusion checkpoint must raise (reference io.py:164 torch.load fails), not silently run on synthetic
+    weights; FF_ALLOW_SYNTH=1 is the explicit opt-in the tests and the bench use."""
+    import models.team29_FreqFusion.io as plug
+    monkeypatch.delenv("FF_ALLOW_SYNTH", raising=False)
+    with pytest.raises(FileNotFoundError):
+        plug._build_state_dict(str(tmp_path / "missing.pth"), str(tmp_path / "no_pretrained"), verbose=False)
+    torch.save({"model_state_dict": {"unrelated.weight": torch.zeros(3)}}, tmp_path / "empty.pth")
+    with pytest.raises(RuntimeError):
+        plug._build_state_dict(str(tmp_path / "empty.pth"), str(tmp_path / "no_pretrained"), verbose=False)
+    monkeypatch.setenv("FF_ALLOW_SYNTH", "1")
+    with pytest.warns(UserWarning):
+        sd = plug._build_state_dict(str(tmp_path / "missing.pth"), str(tmp_path / "no_pretrained"), verbose=False)
+    assert len(sd) > 1000

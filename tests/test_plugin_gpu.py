@@ -39,6 +39,7 @@ def test_plugin_main_writes_reference_png(tmp_path, dev, monkeypatch):
     Image.fromarray(lr_u8[:32, :40]).save(src / "B_small.PNG")               # upper-case extension, non-square
     Image.fromarray(lr_u8).save(src / "ignored.jpg")                         # jpgs are only used when there is no png
     monkeypatch.setenv("FREQFUSION_PRETRAINED", str(tmp_path / "no_such_dir"))  # -> seeded synthetic weights (1234)
+    monkeypatch.setenv("FF_ALLOW_SYNTH", "1")                                    # a missing fusion checkpoint raises otherwise
     plug.main(model_dir=str(tmp_path / "missing_fusion.pth"), input_path=str(src), output_path=str(dst), device=dev)
     assert sorted(os.listdir(dst)) == ["B_small.PNG", "a_case.png"]
     out = np.array(Image.open(dst / "a_case.png").convert("RGB"))
@@ -51,7 +52,12 @@ def test_plugin_main_writes_reference_png(tmp_path, dev, monkeypatch):
 def test_plugin_main_empty_directory(tmp_path, dev, monkeypatch):
     import models.team29_FreqFusion.io as plug
     monkeypatch.setenv("FREQFUSION_PRETRAINED", str(tmp_path / "no_such_dir"))
+    monkeypatch.setenv("FF_ALLOW_SYNTH", "1")
     (tmp_path / "in").mkdir()
+    with pytest.raises(FileNotFoundError):                                       # reference io.py:164: torch.load of a missing file raises
+        monkeypatch.setenv("FF_ALLOW_SYNTH", "0")
+        plug.main(model_dir="nope.pth", input_path=str(tmp_path / "in"), output_path=str(tmp_path / "out0"), device=dev)
+    monkeypatch.setenv("FF_ALLOW_SYNTH", "1")
     plug.main(model_dir="nope.pth", input_path=str(tmp_path / "in"), output_path=str(tmp_path / "out"), device=dev)
     assert os.listdir(tmp_path / "out") == []
 
@@ -87,7 +93,7 @@ def test_oom_falls_back_to_overlap_tiles(tmp_path, dev, hip_model, monkeypatch):
                 raise RuntimeError("HIP out of memory. Tried to allocate 1.00 GiB")
             return hip_model(x)
 
-    monkeypatch.setattr(plug, "_build_and_load", lambda model_dir, device: Flaky())
+    monkeypatch.setattr(plug, "_build_and_load", lambda model_dir, device, rank=0, world=1: Flaky())
     plug.main(model_dir="x.pth", input_path=str(tmp_path / "in"), output_path=str(tmp_path / "out"), device=dev)
     assert calls[0] == (140, 150) and all(c == (128, 128) for c in calls[1:]) and len(calls) == 1 + 4
     got = np.array(Image.open(tmp_path / "out" / "big.png").convert("RGB")).astype(np.int16)
@@ -204,3 +210,72 @@ def test_config3_tiled_image_geometry(dev, hip_model):
     ref = O.tiled_forward(lambda t: hip_model(t.to(dev)).cpu(), lr, tile=256, overlap=32, scale=4)
     assert tuple(got.shape) == (1, 3, 1356, 2040)
     assert (got - ref).abs().max().item() < 2e-6
+
+
+def test_threaded_io_pipeline_matches_serial_loop(tmp_path, dev, hip_model, monkeypatch):
+    """PNG decode / encode on host threads with pinned uint8 staging and HIP-graph replay for repeated
+    shapes must write exactly the files of the reference's serial load -> forward -> save loop (io.py:214-232)."""
+    import models.team29_FreqFusion.io as plug
+    rng = np.random.default_rng(21)
+    (tmp_path / "in").mkdir()
+    sizes = [(40, 48), (40, 48), (33, 37), (40, 48), (64, 32), (40, 48)]         # a repeated shape (graph replay) and odd ones
+    for i, (h, w) in enumerate(sizes):
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(tmp_path / "in" / f"im{i}.png")
+    monkeypatch.setattr(plug, "_build_and_load", lambda model_dir, device, rank=0, world=1: hip_model)
+    monkeypatch.setenv("FF_IO_THREADS", "0")
+    plug.main(model_dir="x.pth", input_path=str(tmp_path / "in"), output_path=str(tmp_path / "serial"), device=dev)
+    monkeypatch.setenv("FF_IO_THREADS", "1")
+    plug.main(model_dir="x.pth", input_path=str(tmp_path / "in"), output_path=str(tmp_path / "threads"), device=dev)
+    assert sorted(os.listdir(tmp_path / "serial")) == sorted(os.listdir(tmp_path / "threads")) == [f"im{i}.png" for i in range(6)]
+    for i, (h, w) in enumerate(sizes):
+        a = np.array(Image.open(tmp_path / "serial" / f"im{i}.png"))
+        b = np.array(Image.open(tmp_path / "threads" / f"im{i}.png"))
+        assert a.shape == (4 * h, 4 * w, 3) and np.array_equal(a, b), i
+
+
+def test_graphed_forward_is_bit_exact_and_survives_other_sizes(dev, hip_model):
+    """model.graphed: replay == eager, bit for bit; a graph captured at one size stays valid after forwards (and captures) at
+    other sizes -- the persistent concat / padded-input buffers are keyed by size."""
+    rng = np.random.default_rng(8)
+    a = torch.from_numpy(rng.random((1, 3, 64, 48), dtype=np.float32)).to(dev)
+    b = torch.from_numpy(rng.random((1, 3, 40, 72), dtype=np.float32)).to(dev)
+    ea, eb = hip_model(a).clone(), hip_model(b).clone()
+    ga = hip_model.graphed(a).clone()
+    gb = hip_model.graphed(b).clone()
+    hip_model(torch.from_numpy(rng.random((1, 3, 56, 56), dtype=np.float32)).to(dev))      # eager at a third size in between
+    ga2 = hip_model.graphed(a).clone()
+    a2 = torch.from_numpy(rng.random((1, 3, 64, 48), dtype=np.float32)).to(dev)
+    ga3 = hip_model.graphed(a2).clone()
+    assert torch.equal(ea, ga) and torch.equal(eb, gb) and torch.equal(ea, ga2)
+    assert torch.equal(hip_model(a2), ga3)
+
+
+def test_config4_image_through_the_plugin(tmp_path, dev, hip_model, monkeypatch, synth_sd):
+    """BASELINE config 4's unit of work at world = 1: one 2040x1356 LR image through main().  The whole image exceeds a kernel
+    size limit (the direct-DFT column tile), so main() takes the reference's fallback (io.py:222-228): 128-px tiles, overlap
+    32, blended on the device -- 17 x 12 = 204 replays of one captured graph.  Checks the output geometry and one 64x64 HR
+    crop from the interior of a tile (no blending there) against the CPU oracle run on that 128x128 LR tile."""
+    import models.team29_FreqFusion.io as plug
+    from oracle import freqfusion_oracle as O
+    import bench
+    lr = (bench.make_tile(44, 2048)[0, :, :1356, :2040].permute(1, 2, 0).numpy() * 255.0).round().astype(np.uint8)   # 1/f noise
+    (tmp_path / "in").mkdir()
+    Image.fromarray(lr).save(tmp_path / "in" / "big_2k.png")
+    monkeypatch.setattr(plug, "_build_and_load", lambda model_dir, device, rank=0, world=1: hip_model)
+    tiles = []
+    orig = plug._tiled_forward
+    monkeypatch.setattr(plug, "_tiled_forward", lambda *a, **k: (tiles.append((k.get("tile_size"), k.get("overlap"))), orig(*a, **k))[1])
+    plug.main(model_dir="x.pth", input_path=str(tmp_path / "in"), output_path=str(tmp_path / "out"), device=dev)
+    out = np.array(Image.open(tmp_path / "out" / "big_2k.png").convert("RGB"))
+    assert out.shape == (4 * 1356, 4 * 2040, 3)
+    assert tiles == [(128, 32)], "expected the whole image to exceed a kernel size limit and take the 128/32 tile path"
+    # tile at (y, x) = (96, 192) covers LR rows 96..224, cols 192..320; its blend ramps are 128 HR px wide, so HR rows
+    # 4*96+128 .. 4*224-128 = 512..768 (cols 896..1152) belong to this tile alone
+    ty, tx = 96, 192
+    assert ty in plug._tile_positions(1356, 128, 96) and tx in plug._tile_positions(2040, 128, 96)
+    tile = torch.from_numpy(lr[ty:ty + 128, tx:tx + 128].astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+    ref = O.forward(synth_sd, tile)
+    ref_u8 = (ref[0].clamp(0, 1).permute(1, 2, 0).numpy() * 255.0).round().astype(np.int16)
+    cy, cx = 4 * ty + 200, 4 * tx + 220
+    d = np.abs(out[cy:cy + 64, cx:cx + 64].astype(np.int16) - ref_u8[200:264, 220:284])
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3, (d.max(), (d > 0).mean())

@@ -46,7 +46,16 @@ def main():
         mb = sum(v["calls"] * v["hbm_MB_per_call_corrected"] for v in sel)
         return {"launches": calls, "hbm_MB_per_launch": mb / max(calls, 1), "hbm_MB_total": mb}
 
-    doc = {"note": __doc__.split("\n\n")[-1].replace("\n", " "), "kernels": kernels,
+    import hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    d = os.path.join(root, "image-super-resolution-2_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    forwards = sum(v["calls"] for k, v in kernels.items() if "fuse_blend" in k)      # launched exactly once per forward
+    doc = {"note": __doc__.split("\n\n")[-1].replace("\n", " "), "csrc_fingerprint": h.hexdigest()[:16], "forwards": forwards,
+           "git": os.environ.get("FF_GIT_HASH", "n/a"), "kernels": kernels,
            "conv_igemm_all_variants": family(lambda k: "conv_igemm" in k or "conv3x3_halo" in k),
            "token_linear_all_variants": family(lambda k: "token_linear" in k),
            "window_attn_all_variants": family(lambda k: "window_attn" in k),
