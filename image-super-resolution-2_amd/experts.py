@@ -14,7 +14,8 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
-from .prep import pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv, pack_token_mlp, pack_token_linear, pack_naf_ffn
+from .prep import (pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv, pack_token_mlp, pack_token_linear, pack_naf_ffn,
+                   pack_win_attn, pack_win_rel)
 
 T = torch.Tensor
 SD = Dict[str, T]
@@ -53,6 +54,19 @@ def _tl(blk: dict, key: str) -> dict:
 def _fast() -> bool:
     """The token-stationary fused kernels exist for the default split-bf16 contraction only."""
     return ops.gemm_mode() == "bf16x3"
+
+
+# Window-resident attention block (LayerNorm + qkv + attention in one launch, csrc/win_attn_fused.hip); FF_WIN_FUSED=0 keeps
+# the two-stage form (token_linear qkv -> window_attn) for A/B measurements.
+_WIN_FUSED = os.environ.get("FF_WIN_FUSED", "1") != "0"
+
+
+def _wf(blk: dict, heads: int, d: int) -> dict:
+    """Lazily packed ff_win_attn_fused weights of blk["qkv"] = (W [3C, C], b)."""
+    pk = blk.get("qkv_wf")
+    if pk is None:
+        pk = blk["qkv_wf"] = pack_win_attn(blk["qkv"][0], blk["qkv"][1], heads, d, d ** -0.5)
+    return pk
 
 
 # =============================================================================================== HAT
@@ -139,16 +153,22 @@ class HatHIP:
     def hab(self, x: T, blk: dict) -> T:
         _, H, W, C = x.shape
         d = C // self.heads
-        if _fast():                                                # LayerNorm inside the qkv launch; xn (conv branch) is its side output
-            qkv, xn = ops.token_linear(x, _tl(blk, "qkv"), gamma=blk["n1"][0], beta=blk["n1"][1], want_xn=True)
-        else:
-            xn = ops.layernorm(x, *blk["n1"])
-            qkv = ops.linear(xn, *blk["qkv"])
         att = ops.empty_like_rows(x)
         s = blk["shift"]
-        ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
-                        kwin=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, heads=self.heads, d=d, scale=d ** -0.5,
-                        rel_table=blk["rel"] if _REL_BIAS else None)
+        if _fast() and _WIN_FUSED:                                 # norm1 + qkv + (S)W-MSA of all six heads in one launch
+            if "relp" not in blk:
+                blk["relp"] = pack_win_rel(blk["rel"], self.ws, self.ws)
+            _, xn = ops.win_attn_fused(x, att, _wf(blk, self.heads, d), blk["relp"], gamma=blk["n1"][0], beta=blk["n1"][1], H=H, W=W,
+                                       Hp=H, Wp=W, win=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, want_xn=True)
+        else:
+            if _fast():                                            # LayerNorm inside the qkv launch; xn (conv branch) is its side output
+                qkv, xn = ops.token_linear(x, _tl(blk, "qkv"), gamma=blk["n1"][0], beta=blk["n1"][1], want_xn=True)
+            else:
+                xn = ops.layernorm(x, *blk["n1"])
+                qkv = ops.linear(xn, *blk["qkv"])
+            ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
+                            kwin=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, heads=self.heads, d=d, scale=d ** -0.5,
+                            rel_table=blk["rel"] if _REL_BIAS else None)
         c1 = ops.conv2d(xn, *blk["cab0"], ksize=(3, 3), pad=(1, 1), act="gelu")
         c2, c2mean = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1), want_pool=True)   # pool from the conv epilogue
         gate = ops.vec_mlp(c2mean, *blk["ca1"], "relu", *blk["ca2"], "sigmoid", post=self.conv_scale)
@@ -292,23 +312,47 @@ class DatHIP:
         _, H, W, C = x.shape
         half, hh = C // 2, self.heads // 2
         d = half // hh
-        if _fast():
-            qkv = ops.token_linear(x, _tl(blk, "qkv"), gamma=blk["n1"][0], beta=blk["n1"][1])   # LayerNorm fused
-        else:
-            qkv = ops.linear(ops.layernorm(x, *blk["n1"]), *blk["qkv"])          # [1,H,W,3C] = q | k | v
-        v = qkv[..., 2 * C:]
-        conv_x = ops.dwconv2d(v, blk["dw"][0], blk["dw"][1], post_scale=blk["dw"][2], post_shift=blk["dw"][3], act="gelu")
-        if blk["spatial"]:
+        fused = blk["spatial"] and _fast() and _WIN_FUSED
+        if fused:
+            # norm1 + qkv + both window-attention branches: two launches (head groups 0-2 on 8x32 windows, 3-5 on 32x8), each
+            # also writes its half of v for the depth-wise conv branch (dat_arch.py:524); q and k never reach memory
             m = max(self.split)
             Hp, Wp = _ceil_to(H, m), _ceil_to(W, m)
             att = ops.empty_like_rows(x)
+            v = ops.empty_like_rows(x)
+            pk = _wf(blk, self.heads, d)
+            if "relp" not in blk:
+                blk["relp"] = []
+                for br in range(2):
+                    wh, ww = (self.split[0], self.split[1]) if br == 0 else (self.split[1], self.split[0])
+                    r6 = torch.zeros(self.heads, blk["rel"][br].shape[1], device=x.device)
+                    r6[hh * br:hh * br + hh] = blk["rel"][br]
+                    blk["relp"].append(pack_win_rel(r6, wh, ww))
             for br in range(2):
                 wh, ww = (self.split[0], self.split[1]) if br == 0 else (self.split[1], self.split[0])
                 sh = (wh // 2, ww // 2) if blk["shifted"] else (0, 0)
-                ops.window_attn(qkv, att, blk["bias"][br], q_off=br * half, k_off=C + br * half, v_off=2 * C + br * half,
-                                o_off=br * half, H=H, W=W, Hp=Hp, Wp=Wp, win=(wh, ww), kwin=(wh, ww), shift=sh,
-                                use_mask=blk["shifted"], heads=hh, d=d, scale=d ** -0.5,
-                                rel_table=blk["rel"][br] if _REL_BIAS else None)
+                ops.win_attn_fused(x, att, pk, blk["relp"][br], gamma=blk["n1"][0], beta=blk["n1"][1], H=H, W=W, Hp=Hp, Wp=Wp,
+                                   win=(wh, ww), shift=sh, use_mask=blk["shifted"], head0=hh * br, nheads=hh, zero_pad=True,
+                                   v_out=v, v_off=0)
+        else:
+            if _fast():
+                qkv = ops.token_linear(x, _tl(blk, "qkv"), gamma=blk["n1"][0], beta=blk["n1"][1])   # LayerNorm fused
+            else:
+                qkv = ops.linear(ops.layernorm(x, *blk["n1"]), *blk["qkv"])          # [1,H,W,3C] = q | k | v
+            v = qkv[..., 2 * C:]
+        conv_x = ops.dwconv2d(v, blk["dw"][0], blk["dw"][1], post_scale=blk["dw"][2], post_shift=blk["dw"][3], act="gelu")
+        if blk["spatial"]:
+            if not fused:
+                m = max(self.split)
+                Hp, Wp = _ceil_to(H, m), _ceil_to(W, m)
+                att = ops.empty_like_rows(x)
+                for br in range(2):
+                    wh, ww = (self.split[0], self.split[1]) if br == 0 else (self.split[1], self.split[0])
+                    sh = (wh // 2, ww // 2) if blk["shifted"] else (0, 0)
+                    ops.window_attn(qkv, att, blk["bias"][br], q_off=br * half, k_off=C + br * half, v_off=2 * C + br * half,
+                                    o_off=br * half, H=H, W=W, Hp=Hp, Wp=Wp, win=(wh, ww), kwin=(wh, ww), shift=sh,
+                                    use_mask=blk["shifted"], heads=hh, d=d, scale=d ** -0.5,
+                                    rel_table=blk["rel"][br] if _REL_BIAS else None)
             ch_in, sp_in = conv_x, att
         else:
             wbd = ops.chan_attn_weights(qkv, 0, C, blk["temp"])

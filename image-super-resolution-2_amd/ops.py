@@ -314,6 +314,41 @@ def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int,
     return out
 
 
+def win_attn_fused(x: T, out: T, pk: dict, rel_padded: T, *, gamma: Optional[T], beta: Optional[T], eps: float = 1e-5,
+                   H: int, W: int, Hp: int, Wp: int, win: Tuple[int, int], shift: Tuple[int, int], use_mask: bool,
+                   head0: int = 0, nheads: Optional[int] = None, o_off: int = 0, zero_pad: bool = False,
+                   want_xn: bool = False, v_out: Optional[T] = None, v_off: int = 0):
+    """LayerNorm + qkv projection + window attention of `nheads` heads in one launch (csrc/win_attn_fused.hip); pk from
+    prep.pack_win_attn, rel_padded from prep.pack_win_rel.  x [B,H,W,K] rows view; out [B,H,W,>= o_off + heads*d].
+    want_xn: also return the normalised rows; v_out: receives v of the processed heads at channel v_off + g*d."""
+    xp, ldx, B, h_, w_, K = _nhwc(x, "win_attn_fused.x")
+    op, ldo, *_ = _nhwc(out, "win_attn_fused.out")
+    if (h_, w_) != (H, W) or tuple(out.shape[:3]) != (B, H, W) or K != pk["K"]:
+        raise _lib.FFError("win_attn_fused: x/out dims mismatch")
+    nheads = pk["heads"] - head0 if nheads is None else nheads
+    if tuple(rel_padded.shape[:2]) != (pk["heads"], 2 * win[0] - 1) or not rel_padded.is_contiguous():
+        raise _lib.FFError("win_attn_fused: rel_padded must be [heads][2wh-1][stride]")
+    if _GEMM_MODE not in ("bf16x3", "bf16"):
+        raise _lib.FFError("win_attn_fused exists for the bf16 contraction modes only")
+    xn, xnp, ldxn = None, None, 0
+    if want_xn:
+        xn = empty_like_rows(x)
+        xnp, ldxn, _, _ = rows_view(xn, "win_attn_fused.xn")
+    vp, ldv = None, 0
+    if v_out is not None:
+        vp, ldv, vb, vh, vw, _ = _nhwc(v_out, "win_attn_fused.v_out")
+        if (vb, vh, vw) != (B, H, W):
+            raise _lib.FFError("win_attn_fused: v_out dims mismatch")
+    _lib.check(_L().ff_win_attn_fused(xp, ldx, op, ldo, o_off, _ptr(gamma), _ptr(beta), float(eps), pk["w"].data_ptr(),
+                                      pk["b"].data_ptr(), rel_padded.data_ptr(), rel_padded.shape[1], rel_padded.shape[2], B, H, W,
+                                      Hp, Wp, win[0], win[1], shift[0], shift[1], int(use_mask), head0, nheads, pk["d"], K,
+                                      int(zero_pad), xnp, ldxn, vp, ldv, v_off, 1 if _GEMM_MODE == "bf16" else 3, _stream()))
+    nwin = B * (Hp // win[0]) * (Wp // win[1])
+    _note(2.0 * nwin * 256 * K * 3 * nheads * pk["d"] + 4.0 * nwin * nheads * 256 * 256 * pk["d"],
+          4.0 * B * H * W * (K * (2 if want_xn else 1) + nheads * pk["d"] * (2 if v_out is not None else 1)))
+    return (out, xn) if want_xn else out
+
+
 def token_mlp(x: T, gamma: T, beta: T, pk: dict, eps: float = 1e-5) -> T:
     """x + fc2(GELU(fc1(LayerNorm(x)))) in one launch (bf16x3 only); pk from prep.pack_token_mlp."""
     xp, ldx, rows, K = rows_view(x, "token_mlp.x")
@@ -720,7 +755,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "linear", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
+for _n in ("conv2d", "linear", "win_attn_fused", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

@@ -136,3 +136,37 @@ def pack_naf_ffn(w4: T, b4: T, w5: T, b5: T) -> dict:
         wh, wl = split_bf16(w5t)
         recs.append(torch.cat([ah, al, bh, bl, wh, wl]))
     return dict(C=C, w=torch.stack(recs).contiguous(), b4=b4.contiguous(), b5=b5.contiguous())
+
+
+def win_rel_stride(ww: int) -> int:
+    """Row stride of the compact bias table of ff_win_attn_fused (>= 2 ww - 1, == ww mod 32: bank-conflict free gathers)."""
+    return {8: 40, 16: 48, 32: 64}[ww]
+
+
+def pack_win_rel(rel: T, wh: int, ww: int) -> T:
+    """[heads][(2wh-1)*(2ww-1)] compact relative-position table -> [heads][2wh-1][stride] (zero padded rows)."""
+    heads = rel.shape[0]
+    rows, cols, st = 2 * wh - 1, 2 * ww - 1, win_rel_stride(ww)
+    out = torch.zeros(heads, rows, st, device=rel.device, dtype=torch.float32)
+    out[:, :, :cols] = rel.reshape(heads, rows, cols)
+    return out.contiguous()
+
+
+def pack_win_attn(wqkv: T, bqkv: Optional[T], heads: int, d: int, scale: float) -> dict:
+    """Weights of ff_win_attn_fused from a fused qkv projection [3C, K] (rows q | k | v, head-major inside each third):
+    tile 3g+j = rows of head g of q / k / v, padded to 32 rows x 192 columns, bf16 hi/lo planes; softmax scale folded into q."""
+    C3, K = wqkv.shape
+    C = C3 // 3
+    assert K <= 192 and heads * d == C and d <= 32
+    dev = wqkv.device
+    wt = torch.zeros(3 * heads, 32, 192, device=dev)
+    bt = torch.zeros(3 * heads, 32, device=dev)
+    for g in range(heads):
+        for j in range(3):
+            rows = slice(j * C + g * d, j * C + (g + 1) * d)
+            sc = scale if j == 0 else 1.0
+            wt[3 * g + j, :d, :K] = wqkv[rows] * sc
+            if bqkv is not None:
+                bt[3 * g + j, :d] = bqkv[rows] * sc
+    hi, lo = split_bf16(wt.reshape(3 * heads, 32 * 192))
+    return dict(w=torch.stack([hi, lo], dim=1).contiguous(), b=bt.reshape(-1).contiguous(), heads=heads, d=d, K=K)

@@ -83,6 +83,29 @@ int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_off, int v_
                          int shift_h, int shift_w, int use_mask, int heads, int d, float scale, int nterms, const float* rel_table,
                          void* stream);
 
+/* Window-resident attention block (csrc/win_attn_fused.hip): LayerNorm -> q/k/v projection -> softmax(q k^T + bias (+mask)) v
+ * for ALL `nheads` heads of one 256-token window per workgroup; the qkv tensor never exists in memory.
+ * Replaces, in one launch, HAB's norm1 + roll + window_partition + WindowAttention.forward up to the output projection
+ * (hat_arch.py:272-303 with :165-192) and DAT's qkv + one SpatialAttention branch (dat_arch.py:501-548 with :290-342).
+ *   x [tokens][ldx] (K <= 192 channels), gamma/beta: LayerNorm (NULL: none), eps.
+ *   w_tiles: bf16 [3*heads_total][2 planes hi,lo][32][192]: tile 3g+0/1/2 = the q / k / v rows of head g (head dim padded
+ *     to 32 rows, K to 192 columns, zero filled; the softmax scale is folded into the q rows and bias);
+ *     bias_padded [3*heads_total*32] (prep.pack_win_attn).
+ *   rel_padded [heads_total][2wh-1][stride]: compact relative-position bias,
+ *     bias[q][k] = rel[head][(qy - ky + wh - 1)*stride + (qx - kx + ww - 1)], stride 40 / 48 / 64 for ww 8 / 16 / 32.
+ *   Window wh x ww = 256 tokens (ww 8, 16 or 32), keys = the query window; cyclic shift + region mask as ff_window_attn.
+ *   Heads head0 .. head0+nheads-1 are processed; head g writes out[token][o_off + g*d .. +d).
+ *   zero_pad_tokens != 0: q/k/v of tokens outside H x W are exactly zero (DAT pads AFTER the projection, dat_arch.py:515-520);
+ *   0: such tokens do not occur (HAT pads the image beforehand).
+ *   xn_out (optional): the LayerNorm'ed rows [tokens][ldxn] (HAT's conv branch input, hat_arch.py:274).
+ *   v_out (optional): v of the processed heads, v_out[token][v_off + g*d ..) (DAT's depth-wise conv branch, dat_arch.py:524).
+ * nterms 3 = split-bf16 (fp32-grade), 1 = plain bf16. */
+int ff_win_attn_fused(const float* x, int ldx, float* out, int ldo, int o_off, const float* gamma, const float* beta,
+                      float eps, const void* w_tiles, const float* bias_padded, const float* rel_padded, int rel_rows,
+                      int rel_stride, int B, int H, int W, int Hp, int Wp, int wh, int ww, int shift_h, int shift_w,
+                      int use_mask, int head0, int nheads, int d, int K, int zero_pad_tokens, float* xn_out, int ldxn,
+                      float* v_out, int ldv, int v_off, int nterms, void* stream);
+
 /* Fused transformer feed-forward on tokens (csrc/token_mlp.hip): out = x + fc2(GELU(fc1(LayerNorm(x)))), bf16x3 MFMA.
  * Replaces hat_arch.py:307 (norm2 + Mlp.forward :88-94 + residual) in one launch; the hidden activation stays on chip.
  * K, N <= 192.  w_tiles: bf16 [hidden_tiles][4][6144] = per 32-wide hidden tile the planes W1_hi, W1_lo ([32][192], zero

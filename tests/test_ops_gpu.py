@@ -615,3 +615,98 @@ def test_dynamic_gates_matches_reference_formula(dev):
     assert (dlt > 1e-5).float().mean().item() <= 1e-4, (dlt > 1e-5).float().mean().item()
     assert (out.max(dim=-1).values >= 0.9 - 1e-6).all(), "at least one expert must be selected per pixel"
     assert out.numel() == 3 * P
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Window-resident attention block (csrc/win_attn_fused.hip): LayerNorm + qkv projection + attention in one launch
+def _ref_ln_qkv(x, g, b, wqkv, bqkv, eps=1e-5):
+    xn = F.layer_norm(x, (x.shape[-1],), g, b, eps)
+    return xn, F.linear(xn, wqkv, bqkv)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3"])
+@pytest.mark.parametrize("H,W,shift", [(32, 48, 0), (32, 48, 8), (16, 16, 8), (256, 256, 8)])
+def test_win_attn_fused_hat(dev, mode, H, W, shift):
+    """HAB attention half (hat_arch.py:272-303 + :165-192) against torch fp32: norm1, qkv, (S)W-MSA with relative-position
+    bias and shift mask; also the normalised rows side output.  256x256 is the bench tile's token grid."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_win_attn, pack_win_rel
+    from oracle import freqfusion_oracle as O
+    prev = ops.gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        heads, d, ws, C = 6, 30, 16, 180
+        x = torch.empty(1, H, W, 192, device=dev)[..., :C]
+        x.copy_(rnd(1, H, W, C, dev=dev, seed=300, scale=1.3) + 0.2)
+        g, b = rnd(C, dev=dev, seed=301) * 0.1 + 1, rnd(C, dev=dev, seed=302) * 0.1
+        wqkv, bqkv = rnd(3 * C, C, dev=dev, seed=303, scale=1.0 / math.sqrt(C)), rnd(3 * C, dev=dev, seed=304, scale=0.1)
+        table = rnd((2 * ws - 1) ** 2, heads, dev=dev, seed=305, scale=0.5)
+        pk = pack_win_attn(wqkv, bqkv, heads, d, d ** -0.5)
+        relp = pack_win_rel(table.t().contiguous(), ws, ws)
+        out = ops.empty_rows((1, H, W, C), dev)
+        out.zero_()
+        _, xn = ops.win_attn_fused(x, out, pk, relp, gamma=g, beta=b, H=H, W=W, Hp=H, Wp=W, win=(ws, ws), shift=(shift, shift),
+                                   use_mask=shift > 0, want_xn=True)
+        xn_ref, qkv = _ref_ln_qkv(x, g, b, wqkv, bqkv)
+        close(xn, xn_ref, 2e-6, "normalised rows")
+        bias = _hat_bias(table, ws, ws, heads)
+        xi = torch.roll(qkv, shifts=(-shift, -shift), dims=(1, 2)) if shift else qkv
+        xw = O._win_split(xi, ws, ws).reshape(-1, ws * ws, 3, heads, d).permute(2, 0, 3, 1, 4)
+        mask = O._region_mask(H, W, ws, ws, ws // 2, ws // 2).to(dev) if shift else None
+        o = O._softmax_attn(xw[0] * d ** -0.5, xw[1], xw[2], bias, mask).transpose(1, 2).reshape(-1, ws * ws, C)
+        o = O._win_merge(o, ws, ws, H, W)
+        if shift:
+            o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+        close(out, o, GEMM_TOL["bf16x3"], "fused window attention")
+    finally:
+        ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("H,W,shifted", [(32, 64, False), (48, 48, True), (64, 32, True), (256, 256, True)])
+def test_win_attn_fused_dat_branches(dev, H, W, shifted):
+    """DAT spatial attention (dat_arch.py:501-548, :290-342): qkv projection of norm1(x), 8x32 / 32x8 branches on channel
+    halves as head groups 0-2 / 3-5, zero q/k/v beyond (H, W), shift + mask, DynamicPosBias table, v side output."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_win_attn, pack_win_rel
+    from oracle import freqfusion_oracle as O
+    prev = ops.gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        C, half, hh, d = 180, 90, 3, 30
+        m = 32
+        Hp, Wp = H + (m - H % m) % m, W + (m - W % m) % m
+        x = torch.empty(1, H, W, 192, device=dev)[..., :C]
+        x.copy_(rnd(1, H, W, C, dev=dev, seed=310, scale=1.3) + 0.2)
+        g, b = rnd(C, dev=dev, seed=311) * 0.1 + 1, rnd(C, dev=dev, seed=312) * 0.1
+        wqkv, bqkv = rnd(3 * C, C, dev=dev, seed=313, scale=1.0 / math.sqrt(C)), rnd(3 * C, dev=dev, seed=314, scale=0.1)
+        pk = pack_win_attn(wqkv, bqkv, 6, d, d ** -0.5)
+        _, qkv = _ref_ln_qkv(x, g, b, wqkv, bqkv)
+        out = torch.zeros(1, H, W, C, device=dev)
+        vout = torch.zeros(1, H, W, 3 * C, device=dev)
+        qkv5 = F.pad(qkv.reshape(1, H, W, 3, C), (0, 0, 0, 0, 0, Wp - W, 0, Hp - H))
+        for br in range(2):
+            wh, ww = (8, 32) if br == 0 else (32, 8)
+            sh, sw = wh // 2, ww // 2
+            rel = rnd(hh, (2 * wh - 1) * (2 * ww - 1), dev=dev, seed=316 + br, scale=0.5)
+            rel6 = torch.zeros(6, rel.shape[1], device=dev)
+            rel6[3 * br:3 * br + 3] = rel
+            ops.win_attn_fused(x, out, pk, pack_win_rel(rel6, wh, ww), gamma=g, beta=b, H=H, W=W, Hp=Hp, Wp=Wp, win=(wh, ww),
+                               shift=(sh, sw) if shifted else (0, 0), use_mask=shifted, head0=3 * br, nheads=3, zero_pad=True,
+                               v_out=vout, v_off=2 * C)
+            cy, cx = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")
+            cy, cx = cy.reshape(-1).to(dev), cx.reshape(-1).to(dev)
+            idx = (cy[:, None] - cy[None, :] + wh - 1) * (2 * ww - 1) + (cx[:, None] - cx[None, :] + ww - 1)
+            bias = rel[:, idx]
+            t = qkv5[..., br * half:(br + 1) * half]
+            if shifted:
+                t = torch.roll(t, shifts=(-sh, -sw), dims=(1, 2))
+            tw = [O._win_split(t[:, :, :, i], wh, ww).reshape(-1, wh * ww, hh, d).transpose(1, 2) for i in range(3)]
+            mask = O._region_mask(Hp, Wp, wh, ww, sh, sw).to(dev) if shifted else None
+            o = O._softmax_attn(tw[0] * d ** -0.5, tw[1], tw[2], bias, mask).transpose(1, 2).reshape(-1, wh * ww, half)
+            o = O._win_merge(o, wh, ww, Hp, Wp)
+            if shifted:
+                o = torch.roll(o, shifts=(sh, sw), dims=(1, 2))
+            close(out[..., br * half:(br + 1) * half], o[:, :H, :W], GEMM_TOL["bf16x3"], f"fused dat branch {br}")
+        close(vout[..., 2 * C:], qkv[..., 2 * C:], GEMM_TOL["bf16x3"], "v side output")
+    finally:
+        ops.set_gemm_mode(prev)

@@ -251,24 +251,58 @@ def test_graphed_forward_is_bit_exact_and_survives_other_sizes(dev, hip_model):
 
 
 def test_config4_image_through_the_plugin(tmp_path, dev, hip_model, monkeypatch, synth_sd):
-    """BASELINE config 4's unit of work at world = 1: one 2040x1356 LR image through main().  The whole image exceeds a kernel
-    size limit (the direct-DFT column tile), so main() takes the reference's fallback (io.py:222-228): 128-px tiles, overlap
-    32, blended on the device -- 17 x 12 = 204 replays of one captured graph.  Checks the output geometry and one 64x64 HR
-    crop from the interior of a tile (no blending there) against the CPU oracle run on that 128x128 LR tile."""
+    """BASELINE config 4's unit of work at world = 1: one 2040x1356 LR image through main(), both branches of the reference's
+    policy (io.py:219-228).  (a) Whole image: fits in 288 GB -- output geometry, range, and agreement of the split-bf16 path
+    with the exact-fp32 contraction on a 512x512 HR crop (the CPU oracle cannot run 2.8 M tokens; whole-image parity at this
+    size is pinned only through these properties).  (b) 'out of memory' on the whole image: 128-px tiles, overlap 32, blended
+    on the device -- 17 x 12 = 204 replays of one captured graph; a 64x64 HR crop from the interior of a tile (no blending
+    there) is compared with the CPU oracle run on that 128x128 LR tile."""
+    import time
     import models.team29_FreqFusion.io as plug
+    from isr2_amd import ops
+    from isr2_amd.model import FreqFusionHIP
     from oracle import freqfusion_oracle as O
     import bench
     lr = (bench.make_tile(44, 2048)[0, :, :1356, :2040].permute(1, 2, 0).numpy() * 255.0).round().astype(np.uint8)   # 1/f noise
     (tmp_path / "in").mkdir()
     Image.fromarray(lr).save(tmp_path / "in" / "big_2k.png")
+    # (a) whole image
     monkeypatch.setattr(plug, "_build_and_load", lambda model_dir, device, rank=0, world=1: hip_model)
-    tiles = []
-    orig = plug._tiled_forward
-    monkeypatch.setattr(plug, "_tiled_forward", lambda *a, **k: (tiles.append((k.get("tile_size"), k.get("overlap"))), orig(*a, **k))[1])
-    plug.main(model_dir="x.pth", input_path=str(tmp_path / "in"), output_path=str(tmp_path / "out"), device=dev)
-    out = np.array(Image.open(tmp_path / "out" / "big_2k.png").convert("RGB"))
+    t0 = time.perf_counter()
+    plug.main(model_dir="x.pth", input_path=str(tmp_path / "in"), output_path=str(tmp_path / "whole"), device=dev)
+    print(f"config 4 image, whole: {time.perf_counter() - t0:.2f} s including PNG decode / encode")
+    whole = np.array(Image.open(tmp_path / "whole" / "big_2k.png").convert("RGB"))
+    assert whole.shape == (4 * 1356, 4 * 2040, 3)
+    lr_t = torch.from_numpy(lr.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0).to(dev)
+    a = hip_model(lr_t)[0, :, 2000:2512, 3000:3512].clone()
+    assert torch.isfinite(a).all() and a.min().item() >= 0.0 and a.max().item() <= 1.0
+    ops.set_gemm_mode("f32")
+    try:
+        exact = FreqFusionHIP(synth_sd, dev)(lr_t)[0, :, 2000:2512, 3000:3512].clone()
+    finally:
+        ops.set_gemm_mode("bf16x3")
+    psnr = O.psnr(a.cpu(), exact.cpu())
+    print("config 4 image, whole: PSNR(bf16x3, f32) on a 512x512 crop =", psnr)
+    assert psnr >= 100.0
+    del exact
+    torch.cuda.empty_cache()
+
+    # (b) the tile path
+    class Limited:                                   # a 16 GB card's behaviour: the whole image does not fit
+        def __call__(self, x):
+            if x.shape[-1] > 128 or x.shape[-2] > 128:
+                raise RuntimeError("HIP out of memory. Tried to allocate 11.30 GiB")
+            return hip_model(x)
+
+        def graphed(self, x):
+            return hip_model.graphed(x)
+
+    monkeypatch.setattr(plug, "_build_and_load", lambda model_dir, device, rank=0, world=1: Limited())
+    t0 = time.perf_counter()
+    plug.main(model_dir="x.pth", input_path=str(tmp_path / "in"), output_path=str(tmp_path / "tiled"), device=dev)
+    print(f"config 4 image, 204 tiles of 128: {time.perf_counter() - t0:.2f} s including PNG decode / encode")
+    out = np.array(Image.open(tmp_path / "tiled" / "big_2k.png").convert("RGB"))
     assert out.shape == (4 * 1356, 4 * 2040, 3)
-    assert tiles == [(128, 32)], "expected the whole image to exceed a kernel size limit and take the 128/32 tile path"
     # tile at (y, x) = (96, 192) covers LR rows 96..224, cols 192..320; its blend ramps are 128 HR px wide, so HR rows
     # 4*96+128 .. 4*224-128 = 512..768 (cols 896..1152) belong to this tile alone
     ty, tx = 96, 192
