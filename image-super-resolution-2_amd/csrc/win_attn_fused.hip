@@ -53,7 +53,8 @@ struct WinFusedParams {
 #define WF_BS_MAX 576
 #define WF_OFF_TOK (WF_OFF_BS + WF_BS_MAX * 4)
 #define WF_OFF_REG (WF_OFF_TOK + 1024)
-#define WF_LDS (WF_OFF_REG + 1024)
+#define WF_OFF_SAME (WF_OFF_REG + 1024)     // [9 regions][8 key tiles] 32-bit masks: which keys of the tile lie in the region
+#define WF_LDS (WF_OFF_SAME + 9 * 8 * 4)
 #define WF_XS_ROW 68
 
 template <int WW, int NTERMS>
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
   float* Bs = reinterpret_cast<float*>(smem + WF_OFF_BS);
   int* ktok = reinterpret_cast<int*>(smem + WF_OFF_TOK);
   int* kreg = reinterpret_cast<int*>(smem + WF_OFF_REG);
+  unsigned* same = reinterpret_cast<unsigned*>(smem + WF_OFF_SAME);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -119,11 +121,19 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
   for (int i = tid; i < ntiles * 32; i += 512) Bs[i] = p.bias ? p.bias[tile0 * 32 + i] : 0.f;
   __syncthreads();
 
+  const bool blk_mask = p.use_mask && (wy == p.nwy - 1 || wx == p.nwx - 1);
+  if (blk_mask) {                                      // key-region bit masks: the shift mask becomes one LDS word per key tile
+    for (int i = wid; i < 72; i += 8) {
+      const int region = i >> 3, t = i & 7;
+      const unsigned long long bal = __ballot(l31 == lane && kreg[32 * t + l31] == region);
+      if (lane == 0) same[i] = (unsigned)bal;
+    }
+    __syncthreads();
+  }
   const int qi = wid * 32 + l31;                       // this lane's window position (query; also one of the wave's keys)
   const int mytok = ktok[qi];
   const bool tvalid = mytok >= 0;
   const int qreg_id = kreg[qi];
-  const bool blk_mask = p.use_mask && (wy == p.nwy - 1 || wx == p.nwx - 1);
   // validity of the wave's 32 tokens as a bit mask (the v tile has tokens in its registers, not in its lanes)
   const unsigned vmask = (unsigned)(__ballot(tvalid) & 0xffffffffu);
   const bool kill_pad = p.zero_pad != 0;               // DAT: q/k/v of the zero-padded tokens are exactly zero
@@ -351,14 +361,21 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
     const float* relp = rel_base + CMAX;
     const unsigned char* kp = KB + l31 * WF_KROWB + 16 * hh;
     const unsigned char* vq = VB + l31 * WF_VROWB + 16 * hh;
-    const int* kregp = kreg + 4 * hh;
+    const unsigned* samep = same + 8 * qreg_id;
 #pragma unroll 1
-    for (int t = 0; t < 8; ++t, relp -= (32 / WW) * RS, kp += WF_KWAVE, vq += 64, kregp += 32) {
+    for (int t = 0; t < 8; ++t, relp -= (32 / WW) * RS, kp += WF_KWAVE, vq += 64) {
       f32x16 st;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = (r & 3) + 8 * (r >> 2);                          // key inside the tile (lane half adds 4 to kx)
         st[r] = relp[-((k / WW) * RS + (k % WW))];
+      }
+      // this tile's V^T operands are requested now and consumed after the softmax: their LDS latency hides behind QK^T
+      bf16x8 vh2[2], vl2[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        vh2[s] = *reinterpret_cast<const bf16x8*>(vq + 32 * s);
+        if (NTERMS == 3) vl2[s] = *reinterpret_cast<const bf16x8*>(vq + 32 * s + WF_VPLB);
       }
       {
 #pragma unroll
@@ -372,10 +389,11 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
           st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[s], st, 0, 0, 0);
         }
       }
-      if (blk_mask) {
+      if (blk_mask) {                                   // keys outside the query's shift region get -100 (hat_arch.py:921-940)
+        const unsigned m = samep[t] >> (4 * hh);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          st[r] += (kregp[(r & 3) + 8 * (r >> 2)] != qreg_id) ? -100.0f : 0.f;
+          st[r] += ((m >> ((r & 3) + 8 * (r >> 2))) & 1u) ? 0.f : -100.0f;
       }
       float mx = st[0];
 #pragma unroll
@@ -398,13 +416,11 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
           ph[j] = h;
           if (NTERMS == 3) pl[j] = (__bf16)(e - (float)h);
         }
-        const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vq + 32 * s);
         if (NTERMS == 3) {
-          const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vq + 32 * s + WF_VPLB);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh2[s], pl, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl2[s], ph, o, 0, 0, 0);
         }
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh2[s], ph, o, 0, 0, 0);
       }
       l_run = l_run * corr + ls;
       m_run = m_new;
