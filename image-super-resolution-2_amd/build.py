@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libff_hip.so")
 SOURCES = ["ff_runtime.hip", "conv_gemm.hip", "conv_gemm_bf16.hip", "conv3x3_halo.hip", "attention.hip", "attention_bf16.hip", "win_attn_fused.hip", "token_mlp.hip", "token_linear.hip", "naf_fused.hip", "norm_pool.hip", "dwconv.hip", "elementwise.hip",
-           "resample.hip", "freq.hip", "fusion_ops.hip"]
+           "resample.hip", "freq.hip", "fusion_ops.hip", "metrics.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -205,7 +205,9 @@ class HatHIP:
         x = ops.conv2d(x, *self.up2, ksize=(3, 3), pad=(1, 1), shuffle=2)
         return ops.conv2d(x, *self.last, ksize=(3, 3), pad=(1, 1))
 
-    def forward(self, lr: T, taps: Optional[dict] = None) -> T:
+    def forward(self, lr: T, taps: Optional[dict] = None, feats: Optional[dict] = None) -> T:
+        """feats (optional dict): receives feats["hat"] = the conv_after_body output [1,Hp,Wp,180] (NHWC), the tensor the
+        reference's forward hook captures for the cached-expert files (expert_loader.py:838)."""
         _, _, h, w = lr.shape
         Hp, Wp = _ceil_to(h, self.ws), _ceil_to(w, self.ws)
         xin = ops.nchw_to_nhwc(lr, Hp, Wp, add=self.neg_mean, pad_mode="reflect")
@@ -224,7 +226,11 @@ class HatHIP:
             else:
                 x = self.group(x, g)
         x = ops.layernorm(x, *self.norm)
-        x = ops.conv2d(x, *self.after, ksize=(3, 3), pad=(1, 1), res=feat)
+        if feats is not None:
+            feats["hat"] = ops.conv2d(x, *self.after, ksize=(3, 3), pad=(1, 1))
+            x = ops.mix2(feats["hat"], feat)
+        else:
+            x = ops.conv2d(x, *self.after, ksize=(3, 3), pad=(1, 1), res=feat)
         sr = self._tail(x)
         return ops.nhwc_to_nchw(sr, 4 * h, 4 * w, clamp01=True)
 
@@ -378,7 +384,7 @@ class DatHIP:
         z = ops.dwconv2d(gte, *blk["sgc"], mul_in=y[..., :c2])                     # dw3x3(LN(x2)) * x1 in one pass
         return ops.linear(z, *blk["fc2"], res=x)
 
-    def forward(self, lr: T, taps: Optional[dict] = None) -> T:
+    def forward(self, lr: T, taps: Optional[dict] = None, feats: Optional[dict] = None) -> T:
         _, _, h, w = lr.shape
         Hp, Wp = _ceil_to(h, 16), _ceil_to(w, 16)
         xin = ops.nchw_to_nhwc(lr, Hp, Wp, add=self.neg_mean, pad_mode="reflect")
@@ -392,7 +398,11 @@ class DatHIP:
                     taps[f"dat.g{g}.b{b}"] = y
             x = ops.conv2d(y, *self.gconv[g], ksize=(3, 3), pad=(1, 1), res=x)
         x = ops.layernorm(x, *self.norm)
-        x = ops.conv2d(x, *self.after, ksize=(3, 3), pad=(1, 1), res=feat)
+        if feats is not None:                                  # expert_loader.py:850: hook on conv_after_body
+            feats["dat"] = ops.conv2d(x, *self.after, ksize=(3, 3), pad=(1, 1))
+            x = ops.mix2(feats["dat"], feat)
+        else:
+            x = ops.conv2d(x, *self.after, ksize=(3, 3), pad=(1, 1), res=feat)
         x = ops.conv2d(x, *self.before_up, ksize=(3, 3), pad=(1, 1), act="lrelu")
         x = ops.conv2d(x, *self.up0, ksize=(3, 3), pad=(1, 1), shuffle=2)
         x = ops.conv2d(x, *self.up2, ksize=(3, 3), pad=(1, 1), shuffle=2)
@@ -457,7 +467,7 @@ class NafnetHIP:
         g = ops.fma3(None, t[..., :c], t[..., c:])
         return ops.linear(g, *k["c5"], res=y, mul=k["gamma"])
 
-    def forward(self, lr: T, taps: Optional[dict] = None) -> T:
+    def forward(self, lr: T, taps: Optional[dict] = None, feats: Optional[dict] = None) -> T:
         _, _, h, w = lr.shape
         H, W = 4 * h, 4 * w
         m = 2 ** len(self.enc_n)
@@ -481,5 +491,7 @@ class NafnetHIP:
             x = ops.conv2d(x, self.ups[lvl], None, shuffle=2, res=skips[-1 - lvl])
             for k in blks:
                 x = self.block(x, k)
+        if feats is not None:
+            feats["nafnet"] = x                                # expert_loader.py:866: the INPUT of the ending conv, [1,Hp,Wp,64]
         x = ops.conv2d(x, *self.ending, ksize=(3, 3), pad=(1, 1), res=inp)
         return ops.nhwc_to_nchw(x, H, W, clamp01=True)

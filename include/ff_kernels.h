@@ -250,6 +250,17 @@ int ff_dynamic_gates(const float* graw, const float* dif, float* gates, long lon
 int ff_fuse_blend(const float* experts9, const float* hier3, const float* guide3, const float* gates3,
                   const float* dif1, float* out3, int Hh, int Wh, int Hl, int Wl, void* stream);
 
+/* Device PSNR / SSIM evaluator (csrc/metrics.hip; reference src/utils/metrics.py:30-52 rgb_to_y, :76-126 calculate_psnr,
+ * :129-190 calculate_ssim_torch).  a, b: planar fp32 images [C][H][W], C = 1 or 3; values are clamped to [0,1], `crop` border
+ * pixels are dropped, use_y != 0 converts RGB to BT.601 luma first.  work: ff_metric_workspace(C,H,W,crop) doubles.
+ * ff_psnr_mse writes the mean squared error, ff_ssim_mean the mean of the SSIM map (11-tap separable Gaussian gauss11,
+ * zero padding) to a device double; both are deterministic (fixed-order double-precision reduction). */
+int ff_metric_workspace(int C, int H, int W, int crop);
+int ff_psnr_mse(const float* a, const float* b, int C, int H, int W, int crop, int use_y, double* work, int nwork, double* out_mse,
+                void* stream);
+int ff_ssim_mean(const float* a, const float* b, int C, int H, int W, int crop, int use_y, const float* gauss11, double* work,
+                 int nwork, double* out_ssim, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

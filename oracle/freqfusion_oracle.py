@@ -228,7 +228,10 @@ def hat_forward(sd: SD, img: T, p: str = HAT_P, groups: int = 12, depth: int = 6
         if taps is not None and g == 0:
             taps["hat.g0.out"] = x
     x = _tok2img(_ln(x, sd, p + "norm"), h, w)
-    x = _conv(x, sd, p + "conv_after_body") + feat
+    cab = _conv(x, sd, p + "conv_after_body")
+    if taps is not None:
+        taps["feat.hat"] = cab                 # what the reference's forward hook on conv_after_body captures (expert_loader.py:838)
+    x = cab + feat
     return _sr_tail(x, sd, p) + mean
 
 
@@ -340,7 +343,10 @@ def dat_forward(sd: SD, img: T, p: str = DAT_P, groups: int = 6, depth: int = 6,
                 taps[f"dat.g{g}.b{b}"] = y
         x = x + _img2tok(_conv(_tok2img(y, h, w), sd, f"{p}layers.{g}.conv"))
     x = _tok2img(_ln(x, sd, p + "norm"), h, w)
-    x = _conv(x, sd, p + "conv_after_body") + feat
+    cab = _conv(x, sd, p + "conv_after_body")
+    if taps is not None:
+        taps["feat.dat"] = cab                 # expert_loader.py:850
+    x = cab + feat
     return _sr_tail(x, sd, p) + mean
 
 
@@ -386,6 +392,8 @@ def nafnet_forward(sd: SD, img: T, p: str = NAF_P, enc=(2, 2, 4, 8), mid: int = 
         x = F.pixel_shuffle(_conv(x, sd, f"{p}ups.{lvl}.0"), 2) + skips[-1 - lvl]
         for b in range(nb):
             x = naf_block(x, sd, f"{p}decoders.{lvl}.{b}.")
+    if taps is not None:
+        taps["feat.nafnet"] = x                # the INPUT of the ending conv (expert_loader.py:866, capture_input=True)
     x = _conv(x, sd, p + "ending") + inp
     return x[:, :, :h, :w]
 
@@ -404,6 +412,16 @@ def experts_forward(sd: SD, lr: T, taps: Optional[dict] = None) -> Dict[str, T]:
     out["dat"] = dat_forward(sd, xp, taps=taps)[:, :, :4 * h, :4 * w].clamp(0, 1)
     out["nafnet"] = nafnet_sr_forward(sd, lr, taps=taps).clamp(0, 1)
     return out
+
+
+def experts_forward_with_features(sd: SD, lr: T):
+    """ExpertEnsemble.forward_all_with_hooks (expert_loader.py:894-951): the three SR outputs plus the hook-captured
+    features, each bilinearly resized to the LR resolution -- the payload of the cached-expert files."""
+    taps: dict = {}
+    out = experts_forward(sd, lr, taps)
+    h, w = lr.shape[-2:]
+    feats = {k: _bilinear(taps["feat." + k], (h, w)) for k in ("hat", "dat", "nafnet")}
+    return out, feats
 
 
 # ----------------------------------------------------------------------------- frequency bands
@@ -709,3 +727,42 @@ def psnr(a: T, b: T, crop: int = 0) -> float:
         a, b = a[..., crop:-crop, crop:-crop], b[..., crop:-crop, crop:-crop]
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)
+
+
+# ================================================================================================ quality metrics
+# Restatement of src/utils/metrics.py: rgb_to_y :30-52, calculate_psnr :76-126, calculate_ssim's torch path
+# :129-190 (used when scikit-image is absent).  Checker for the device evaluator (isr2_amd/metrics.py); pinned by
+# tests/golden/metrics.npz (generated from the imported reference).
+def rgb_to_y(img: T) -> T:
+    r, g, b = (img[0:1], img[1:2], img[2:3]) if img.ndim == 3 else (img[:, 0:1], img[:, 1:2], img[:, 2:3])
+    return (65.481 * r + 128.553 * g + 24.966 * b + 16.0) / 255.0
+
+
+def _metric_prep(a: T, b: T, crop: int, ych: bool):
+    a, b = a.clamp(0, 1), b.clamp(0, 1)
+    if a.ndim == 3:
+        a, b = a.unsqueeze(0), b.unsqueeze(0)
+    if crop > 0:
+        a, b = a[:, :, crop:-crop, crop:-crop], b[:, :, crop:-crop, crop:-crop]
+    if ych and a.size(1) == 3:
+        a, b = rgb_to_y(a), rgb_to_y(b)
+    return a, b
+
+
+def metric_psnr(a: T, b: T, crop_border: int = 0, test_y_channel: bool = False) -> float:
+    a, b = _metric_prep(a, b, crop_border, test_y_channel)
+    mse = torch.mean((a - b) ** 2).item()
+    return float("inf") if mse < 1e-10 else 10 * math.log10(1.0 / mse)
+
+
+def metric_ssim(a: T, b: T, crop_border: int = 0, test_y_channel: bool = False, window_size: int = 11, sigma: float = 1.5) -> float:
+    a, b = _metric_prep(a, b, crop_border, test_y_channel)
+    ch = a.size(1)
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    win = g.mm(g.t()).float()[None, None].expand(ch, 1, window_size, window_size).contiguous()
+    conv = lambda t: F.conv2d(t, win, padding=window_size // 2, groups=ch)      # noqa: E731
+    mu1, mu2 = conv(a), conv(b)
+    s11, s22, s12 = conv(a * a) - mu1 ** 2, conv(b * b) - mu2 ** 2, conv(a * b) - mu1 * mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 ** 2 + mu2 ** 2 + c1) * (s11 + s22 + c2))).mean().item()

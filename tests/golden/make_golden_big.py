@@ -4,6 +4,7 @@
     python tests/golden/make_golden_big.py config3     # BASELINE config 3: reference io._tiled_forward(model, lr, 256, 32)
                                                        #   on one 510x339 1/f image (6 tiles), ~15-20 min
     python tests/golden/make_golden_big.py b2          # a B=2 48x48 batch through the reference (batched-forward parity)
+    python tests/golden/make_golden_big.py hooks48     # the cached-expert features of forward_all_with_hooks
 
 A 1024x1024x3 fp32 output is 12.6 MB, so only data a test can check cheaply is stored:
   * for every tap (same names as make_golden.py): 4096 seeded samples + (mean, mean|x|, L2) over the whole tensor,
@@ -120,6 +121,21 @@ def b2(model, sd):
     return {"ref_batched_vs_single_max_abs": float((out - one).abs().max())}
 
 
+def hooks48(model, sd):
+    """ExpertEnsemble.forward_all_with_hooks (expert_loader.py:894-951) on the 48x48 uint8 case: the cached-expert features
+    (conv_after_body outputs of HAT / DAT, the input of NAFNet's ending conv, each bilinearly resized to LR resolution)."""
+    lr = make_input("u8", 48, 48, 0)
+    ens = model.expert_ensemble
+    with contextlib.redirect_stdout(_io.StringIO()):
+        outputs, feats = ens.forward_all_with_hooks(lr)
+    blob = {"lr": lr.numpy()}
+    # (the SR outputs of the same case are in c48_u8.npz)
+    for k, v in feats.items():
+        blob["feat/" + k] = v.detach().numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "hooks48.npz"), **blob)
+    return {k: list(v.shape) for k, v in feats.items()}
+
+
 def main():
     what = sys.argv[1:] or ["tile256"]
     torch.manual_seed(0)
@@ -129,7 +145,7 @@ def main():
     rp = os.path.join(HERE, "big_pinning_report.json")
     report = json.load(open(rp)) if os.path.exists(rp) else {}
     for wname in what:
-        report[wname] = {"tile256": tile256, "config3": config3, "b2": b2}[wname](model, sd)
+        report[wname] = {"tile256": tile256, "config3": config3, "b2": b2, "hooks48": hooks48}[wname](model, sd)
         json.dump(report, open(rp, "w"), indent=1)
 
 
