@@ -351,6 +351,9 @@ static int dispatch_bf(const ConvBfParams& p, bool vec4, int cfg, hipStream_t st
     case 2: return launch_bf<128, 64, 2, 2, NT>(p, vec4, st);
     case 3: return launch_bf<256, 32, 4, 1, NT>(p, vec4, st);
     case 4: return launch_bf<256, 192, 4, 2, NT>(p, vec4, st);
+    case 5: return launch_bf<128, 128, 2, 4, NT>(p, vec4, st);      // 8 waves (two per SIMD), 64x32 per wave
+    case 6: return launch_bf<256, 128, 4, 2, NT>(p, vec4, st);      // 8 waves, 64x64 per wave
+    case 7: return launch_bf<128, 64, 4, 2, NT>(p, vec4, st);       // 8 waves, 32x32 per wave
     default: ff_set_error("ff_conv2d_bf16s: bad tile_hint %d", cfg); return FF_ERR_ARG;
   }
 }
@@ -388,13 +391,15 @@ extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_
   if (cfg <= 0) {
     // measured on MI355X (profiles/r01_gemm_shapes_bf16x3_v2.txt): 128x128 tiles win whenever N pads well or K is long
     const int r192 = Cout % 192, r128 = Cout % 128;
+    // r2 (profiles/r02_gemm_shapes_8wave.txt): the 8-wave forms of the 128-row tiles (two waves per SIMD: one wave's operand
+    // reads and global-load waits hide behind the other's MFMAs) beat the 4-wave forms on every 1x1 shape: cfg 5 replaces 1, 7 replaces 2
     if (Cout <= 32) cfg = 3;
-    else if (Cout <= 64) cfg = 2;
-    else if (r128 == 0) cfg = 1;
+    else if (Cout <= 64) cfg = 7;
+    else if (r128 == 0) cfg = 5;
     // measured (profiles/r01_gemm_shapes_bf16x3_v3.txt): 256x192 wins for N <= 192 or long K; 128x128 for wide N at K = 180
     else if (vec4 && p.M >= 256 * 64 && (r192 == 0 || r192 > 128) && (Cout <= 192 || p.K >= 320)) cfg = 4;
-    else if (Cout > 256 || (Cout > 128 && p.K >= 512)) cfg = 1;
-    else cfg = 2;
+    else if (Cout > 256 || (Cout > 128 && p.K >= 512)) cfg = 5;
+    else cfg = 7;
   }
   switch (nterms) {
     case 1: return dispatch_bf<1>(p, vec4, cfg, st);

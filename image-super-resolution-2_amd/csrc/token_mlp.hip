@@ -309,6 +309,346 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(TokenMlpParams p) {
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Attention output projection + residuals + norm2 + MLP in ONE launch (HAB / OCAB tail, hat_arch.py:303-307):
+//     x1  = shortcut + proj(att) + conv_x * conv_scale            (:305; the conv term is absent in OCAB :436)
+//     out = x1 + fc2(GELU(fc1(LayerNorm(x1))))                    (:307 / :437)
+// The two-kernel form (token_linear proj -> token_mlp) wrote x1 (47 MB) and read it back; here the six 32-channel tiles of
+// proj^T[channel][token] stay in the 96 output accumulators: the residuals are added there, the LayerNorm statistics are taken
+// from them (a lane holds 96 of its token's 192 padded channels, the other half sits in lane + 32), the normalised values
+// become the fc1 operand straight from the accumulator registers -- registers 8s..8s+7 of tile n are k-step 2n+s, so fc1's
+// K columns are stored in the matching permuted order (prep.pack_token_projmlp) -- and x1 itself remains in the
+// accumulators as the final residual.  att rows are the B operand of the projection (hi in registers, lo in the wave's
+// LDS rows, like x in token_mlp); the projection's weight tiles use the W1 / W2 image areas as a 2-slot ring.
+struct TokenProjMlpParams {
+  const float* att; const float* x; const float* c2; const float* rs2;   // c2 / rs2 may be NULL (OCAB)
+  float* out;
+  const float* gamma; const float* beta;
+  const __bf16* wp;       // proj tiles [6][2 planes][32][192]
+  const float* bp;        // [192] proj bias, zero padded
+  const __bf16* w;        // MLP tiles as in TokenMlpParams, W1 columns permuted
+  const float* b1; const float* b2;
+  long long M;
+  int lda, ldx, ldc, ldo, K, N, HT;
+  float eps;
+};
+
+__global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int W1B = W1PL * 16, W2B = W2PL * 16;
+  unsigned char* W1s = smem;
+  unsigned char* W2s = smem + 2 * W1B;
+  unsigned char* XLs = smem + 2 * W1B + 2 * W2B;
+  float* B1s = reinterpret_cast<float*>(XLs + 8 * 32 * XLROWB);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const long long tok0 = (long long)blockIdx.x * 256 + wid * 32;
+
+  int off1[4], off2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int s = (wid + 8 * i) * 64 + lane;
+    if (s >= 2 * W1PL) s = 2 * W1PL - 1;
+    int plane = s / W1PL, t = s - plane * W1PL, row = t / W1SLOTS, q = t - row * W1SLOTS;
+    if (q > 23) q = 23;
+    off1[i] = plane * TILE_ELEMS + row * 192 + q * 8;
+    s = (wid + 8 * i) * 64 + lane;
+    if (s >= 2 * W2PL) s = 2 * W2PL - 1;
+    plane = s / W2PL; t = s - plane * W2PL; row = t / W2SLOTS; q = t - row * W2SLOTS;
+    if (q > 3) q = 3;
+    off2[i] = (2 + plane) * TILE_ELEMS + row * 32 + q * 8;
+  }
+  auto dma_w1 = [&](int ht) {
+    const __bf16* rec = p.w + (long long)ht * (4 * TILE_ELEMS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (wid + 8 * i < W1PIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + off1[i]),
+                                         (__attribute__((address_space(3))) void*)(W1s + (wid + 8 * i) * 1024), 16, 0, 0);
+  };
+  auto dma_w2 = [&](int ht) {
+    const __bf16* rec = p.w + (long long)ht * (4 * TILE_ELEMS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (wid + 8 * i < W2PIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + off2[i]),
+                                         (__attribute__((address_space(3))) void*)(W2s + (wid + 8 * i) * 1024), 16, 0, 0);
+  };
+  // projection tile n (a W1-format image) into ring slot 0 = the W1 area, 1 = the W2 area (30 720 B >= 25 600 B)
+  auto dma_proj = [&](int n, int slot) {
+    const __bf16* rec = p.wp + (long long)n * (2 * TILE_ELEMS);
+    unsigned char* dst = slot ? W2s : W1s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (wid + 8 * i < W1PIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + off1[i]),
+                                         (__attribute__((address_space(3))) void*)(dst + (wid + 8 * i) * 1024), 16, 0, 0);
+  };
+  dma_proj(0, 0);
+  for (int i = tid; i < p.HT * 32; i += 512) B1s[i] = p.b1[i];
+
+  // ---- att rows -> split fragments (hi registers, lo in the wave's LDS rows) ---------------------------------------
+  bf16x8 xh[TM_KS];
+  unsigned char* xl_row = XLs + (size_t)(wid * 32 + l31) * XLROWB + 16 * hh;
+  {
+    float v[TM_KS][8];
+    ff_wave_rows_to_frags<3>(p.att, p.lda, tok0, p.M, p.K, reinterpret_cast<float*>(XLs + (size_t)wid * 32 * XLROWB), lane, v);
+#pragma unroll
+    for (int st = 0; st < TM_KS; ++st) {
+      bf16x8 lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = v[st][j];
+        const __bf16 h = (__bf16)f;
+        xh[st][j] = h;
+        lo[j] = (__bf16)(f - (float)h);
+      }
+      *reinterpret_cast<bf16x8*>(xl_row + 32 * st) = lo;
+    }
+  }
+
+  // ---- proj^T tiles into the output accumulators -------------------------------------------------------------------
+  f32x16 oacc[6];
+#pragma unroll
+  for (int n = 0; n < 6; ++n) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // tile n landed everywhere; every wave is past tile n-1
+    if (n + 1 < 6) dma_proj(n + 1, (n + 1) & 1);
+    const float* bpn = p.bp + n * 32 + 4 * hh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[n][r] = bpn[(r & 3) + 8 * (r >> 2)];
+    const unsigned char* ap = ((n & 1) ? W2s : W1s) + l31 * W1ROWB + 16 * hh;
+    bf16x8 fa[2], fl[2], fx[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      fa[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u);
+      fl[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u + W1B);
+      fx[u] = *reinterpret_cast<const bf16x8*>(xl_row + 32 * u);
+    }
+#pragma unroll
+    for (int st = 0; st < TM_KS; ++st) {
+      const bf16x8 ah = fa[st & 1], al = fl[st & 1], xl = fx[st & 1];
+      if (st + 2 < TM_KS) {
+        fa[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2));
+        fl[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2) + W1B);
+        fx[st & 1] = *reinterpret_cast<const bf16x8*>(xl_row + 32 * (st + 2));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, oacc[n], 0, 0, 0);
+      oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], oacc[n], 0, 0, 0);
+      oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], oacc[n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // both image areas are free again: start the MLP's first tiles
+  dma_w1(0);
+  dma_w2(0);
+
+  // ---- residuals: coalesced float4 loads (lane = token row lane>>3 (+8i), channel quad) go through the wave's own LDS rows
+  //      (the att_lo image is dead) and come back in accumulator order: x1 = proj + shortcut + conv * scale ------------
+  {
+    float* tr = reinterpret_cast<float*>(XLs + (size_t)wid * 32 * XLROWB);      // [32 tokens][36]
+    const int tq = lane >> 3, q4 = 4 * (lane & 7);
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const int c4 = n * 32 + q4;
+      const bool cok = c4 < p.N;
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+      if (p.c2 && cok) sc = *reinterpret_cast<const f32x4*>(p.rs2 + c4);
+      f32x4 rq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long tk = tok0 + tq + 8 * i;
+        const bool ok = cok && tk < p.M;
+        f32x4 r0 = *reinterpret_cast<const f32x4*>(p.x + (ok ? tk * p.ldx + c4 : 0));
+        if (p.c2) r0 += *reinterpret_cast<const f32x4*>(p.c2 + (ok ? tk * p.ldc + c4 : 0)) * sc;
+        rq[i] = ok ? r0 : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(tr + (tq + 8 * i) * 36 + q4) = rq[i];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(tr + l31 * 36 + 8 * g + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) oacc[n][4 * g + e] += u[e];
+      }
+    }
+  }
+  // ---- LayerNorm(x1) from the accumulators -> fc1 operand (hi registers, lo rows) -------------------------------------
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += (n * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < p.K) ? oacc[n][r] : 0.f;
+    s += __shfl_xor(s, 32);
+    const float mean = s / (float)p.K;
+    float qv = 0.f;
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = (n * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < p.K) ? oacc[n][r] - mean : 0.f;
+        qv += d * d;
+      }
+    qv += __shfl_xor(qv, 32);
+    const float rstd = 1.0f / sqrtf(qv / (float)p.K + p.eps);
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 lo;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          const int c0 = n * 32 + 8 * (2 * s2 + g2) + 4 * hh;           // channels of registers 8 s2 + 4 g2 .. + 3
+          const bool cok = c0 < p.K;
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + (cok ? c0 : 0));
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + (cok ? c0 : 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float f = cok ? (oacc[n][8 * s2 + 4 * g2 + e] - mean) * rstd * g4[e] + b4[e] : 0.f;
+            const __bf16 h = (__bf16)f;
+            xh[2 * n + s2][4 * g2 + e] = h;
+            lo[4 * g2 + e] = (__bf16)(f - (float)h);
+          }
+        }
+        *reinterpret_cast<bf16x8*>(xl_row + 32 * (2 * n + s2)) = lo;
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- the MLP over hidden tiles: identical to token_mlp_kernel (W1 columns are permuted to the operand order above) ----
+  for (int ht = 0; ht < p.HT; ++ht) {
+    f32x16 hacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hacc[r] = B1s[ht * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+    {
+      const unsigned char* ap = W1s + l31 * W1ROWB + 16 * hh;
+      bf16x8 fa[2], fl[2], fx[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        fa[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u);
+        fl[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u + W1B);
+        fx[u] = *reinterpret_cast<const bf16x8*>(xl_row + 32 * u);
+      }
+#pragma unroll
+      for (int st = 0; st < TM_KS; ++st) {
+        const bf16x8 ah = fa[st & 1], al = fl[st & 1], xl = fx[st & 1];
+        if (st + 2 < TM_KS) {
+          fa[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2));
+          fl[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2) + W1B);
+          fx[st & 1] = *reinterpret_cast<const bf16x8*>(xl_row + 32 * (st + 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], hacc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ht + 1 < p.HT) dma_w1(ht + 1);
+    bf16x8 gh[2], gl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float g = ff_gelu_fast(hacc[8 * s + j]);
+        const __bf16 h = (__bf16)g;
+        gh[s][j] = h;
+        gl[s][j] = (__bf16)(g - (float)h);
+      }
+    {
+      const unsigned char* ap = W2s + l31 * W2ROWB + 16 * hh;
+      bf16x8 fa[2], fl[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        fa[u] = *reinterpret_cast<const bf16x8*>(ap + (u >> 1) * 32 * W2ROWB + 32 * (u & 1));
+        fl[u] = *reinterpret_cast<const bf16x8*>(ap + (u >> 1) * 32 * W2ROWB + 32 * (u & 1) + W2B);
+      }
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int n = u >> 1, s2 = u & 1;
+        const bf16x8 ah = fa[u & 1], al = fl[u & 1];
+        if (u + 2 < 12) {
+          fa[u & 1] = *reinterpret_cast<const bf16x8*>(ap + ((u + 2) >> 1) * 32 * W2ROWB + 32 * ((u + 2) & 1));
+          fl[u & 1] = *reinterpret_cast<const bf16x8*>(ap + ((u + 2) >> 1) * 32 * W2ROWB + 32 * ((u + 2) & 1) + W2B);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl[s2], oacc[n], 0, 0, 0);
+        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh[s2], oacc[n], 0, 0, 0);
+        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh[s2], oacc[n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ht + 1 < p.HT) dma_w2(ht + 1);
+  }
+
+  // ---- epilogue: out = accumulators (x1 + fc2 part) + b2, transposed through LDS into 128-byte row segments ------------
+  {
+    float* tr = reinterpret_cast<float*>(smem) + wid * (32 * 36);
+    const int tq = lane >> 3, q4 = 4 * (lane & 7);
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const int c4 = n * 32 + q4;
+      const bool cok = c4 < p.N;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.b2 + (cok ? c4 : 0));
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = oacc[n][4 * g + e];
+        *reinterpret_cast<f32x4*>(tr + l31 * 36 + 8 * g + 4 * hh) = v4;
+      }
+      f32x4 ov[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ov[i] = *reinterpret_cast<const f32x4*>(tr + (tq + 8 * i) * 36 + q4) + b4;
+      if (cok) {
+        float* op = p.out + (tok0 + tq) * p.ldo + c4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (tok0 + tq + 8 * i < p.M) *reinterpret_cast<f32x4*>(op + (long long)(8 * i) * p.ldo) = ov[i];
+      }
+    }
+  }
+}
+
+extern "C" int ff_token_projmlp(const float* att, int lda, const float* x, int ldx, const float* c2, int ldc, const float* c2_scale,
+                                float* out, int ldo, long long M, int K, int hidden_tiles, const void* proj_tiles,
+                                const float* proj_bias_padded, const float* gamma, const float* beta, float eps,
+                                const void* mlp_tiles, const float* b1_padded, const float* b2, void* stream) {
+  FF_CHECK_ARG(att && x && out && proj_tiles && proj_bias_padded && gamma && beta && mlp_tiles && b1_padded && b2, "ff_token_projmlp: null pointer");
+  FF_CHECK_ARG(M > 0 && K > 0 && K <= TM_KP && K % 4 == 0 && hidden_tiles > 0, "ff_token_projmlp: needs K <= 192 (K %% 4 == 0)");
+  FF_CHECK_ARG(lda >= K && lda % 4 == 0 && ldx >= K && ldx % 4 == 0 && ldo >= K && ldo % 4 == 0, "ff_token_projmlp: rows must be 16-byte aligned");
+  FF_CHECK_ARG((((uintptr_t)att) & 15) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "ff_token_projmlp: 16-byte aligned tensors");
+  FF_CHECK_ARG((c2 == nullptr) == (c2_scale == nullptr), "ff_token_projmlp: c2 / c2_scale come together");
+  FF_CHECK_ARG(!c2 || (ldc >= K && ldc % 4 == 0 && (((uintptr_t)c2) & 15) == 0 && (((uintptr_t)c2_scale) & 15) == 0), "ff_token_projmlp: c2 rows must be 16-byte aligned");
+  FF_CHECK_ARG((((uintptr_t)proj_tiles) & 15) == 0 && (((uintptr_t)mlp_tiles) & 15) == 0 && (((uintptr_t)gamma) & 15) == 0 &&
+               (((uintptr_t)beta) & 15) == 0 && (((uintptr_t)b2) & 15) == 0, "ff_token_projmlp: weights / gamma / beta / b2 must be 16-byte aligned");
+  TokenProjMlpParams p;
+  p.att = att; p.x = x; p.c2 = c2; p.rs2 = c2_scale; p.out = out; p.gamma = gamma; p.beta = beta;
+  p.wp = (const __bf16*)proj_tiles; p.bp = proj_bias_padded; p.w = (const __bf16*)mlp_tiles; p.b1 = b1_padded; p.b2 = b2;
+  p.M = M; p.lda = lda; p.ldx = ldx; p.ldc = ldc; p.ldo = ldo; p.K = K; p.N = K; p.HT = hidden_tiles; p.eps = eps;
+  const size_t lds = (size_t)(2 * W1PL + 2 * W2PL) * 16 + (size_t)8 * 32 * XLROWB + (size_t)hidden_tiles * 32 * 4;
+  FF_CHECK_ARG(lds <= 160 * 1024, "ff_token_projmlp: hidden too large for the LDS image");
+  const long long nblk = (M + 255) / 256;
+  FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_projmlp: grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_projmlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { ff_set_error("ff_token_projmlp: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(token_projmlp_kernel, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  FF_LAUNCH_CHECK("ff_token_projmlp");
+  return FF_OK;
+}
+
 extern "C" int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long long M, int K, int hidden_tiles, int N,
                             const float* gamma, const float* beta, float eps, const void* w_tiles, const float* b1_padded,
                             const float* b2, void* stream) {

@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from .prep import (pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv, pack_token_mlp, pack_token_linear, pack_naf_ffn,
-                   pack_win_attn, pack_win_rel)
+                   pack_win_attn, pack_win_rel, pack_token_projmlp)
 
 T = torch.Tensor
 SD = Dict[str, T]
@@ -59,6 +59,16 @@ def _fast() -> bool:
 # Window-resident attention block (LayerNorm + qkv + attention in one launch, csrc/win_attn_fused.hip); FF_WIN_FUSED=0 keeps
 # the two-stage form (token_linear qkv -> window_attn) for A/B measurements.
 _WIN_FUSED = os.environ.get("FF_WIN_FUSED", "1") != "0"
+# Attention projection + residuals + norm2 + MLP in one launch (csrc/token_mlp.hip: token_projmlp_kernel); 0 = two launches
+_PROJ_MLP = os.environ.get("FF_PROJ_MLP", "1") != "0"
+
+
+def _pm(blk: dict) -> dict:
+    pk = blk.get("projmlp_pk")
+    if pk is None:
+        pk = blk["projmlp_pk"] = pack_token_projmlp(blk["proj"][0], blk["proj"][1], blk["fc1"][0], blk["fc1"][1],
+                                                    blk["fc2"][0], blk["fc2"][1])
+    return pk
 
 
 def _wf(blk: dict, heads: int, d: int) -> dict:
@@ -172,6 +182,8 @@ class HatHIP:
         c1 = ops.conv2d(xn, *blk["cab0"], ksize=(3, 3), pad=(1, 1), act="gelu")
         c2, c2mean = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1), want_pool=True)   # pool from the conv epilogue
         gate = ops.vec_mlp(c2mean, *blk["ca1"], "relu", *blk["ca2"], "sigmoid", post=self.conv_scale)
+        if _fast() and _PROJ_MLP:                                  # proj + both residuals + norm2 + MLP: x1 never reaches memory
+            return ops.token_projmlp(att, x, _pm(blk), blk["n2"][0], blk["n2"][1], c2=c2, c2_scale=gate.reshape(-1))
         if _fast():                                                # shortcut + conv_x*conv_scale + proj(attention), one launch
             x = ops.token_linear(att, _tl(blk, "proj"), res=x, res2=c2, res2_scale=gate.reshape(-1))
         else:
@@ -189,6 +201,8 @@ class HatHIP:
         att = ops.empty_like_rows(x)
         ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
                         kwin=(self.ows, self.ows), shift=(0, 0), use_mask=False, heads=self.heads, d=d, scale=d ** -0.5)
+        if _fast() and _PROJ_MLP:
+            return ops.token_projmlp(att, x, _pm(blk), blk["n2"][0], blk["n2"][1])
         x = ops.token_linear(att, _tl(blk, "proj"), res=x) if _fast() else ops.linear(att, *blk["proj"], res=x)
         return self._mlp(x, blk)
 

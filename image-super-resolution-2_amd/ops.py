@@ -362,6 +362,29 @@ def token_mlp(x: T, gamma: T, beta: T, pk: dict, eps: float = 1e-5) -> T:
     return out
 
 
+def token_projmlp(att: T, x: T, pk: dict, gamma: T, beta: T, *, c2: Optional[T] = None, c2_scale: Optional[T] = None,
+                  eps: float = 1e-5) -> T:
+    """x1 = x + proj(att) + c2 * c2_scale; return x1 + fc2(GELU(fc1(LayerNorm(x1)))) in one launch (bf16x3); pk from
+    prep.pack_token_projmlp."""
+    ap, lda, rows, K = rows_view(att, "token_projmlp.att")
+    xp, ldx, xr, xk = rows_view(x, "token_projmlp.x")
+    if xr != rows or xk != K or K != pk["mlp"]["K"]:
+        raise _lib.FFError("token_projmlp: shape mismatch")
+    cp, ldc = None, 0
+    if c2 is not None:
+        cp, ldc, cr, ck = rows_view(c2, "token_projmlp.c2")
+        if cr != rows or ck != K or c2_scale is None or c2_scale.numel() != K:
+            raise _lib.FFError("token_projmlp: c2 shape mismatch")
+    out = empty_like_rows(x)
+    op_, ldo_, _, _ = rows_view(out, "token_projmlp.out")
+    m = pk["mlp"]
+    _lib.check(_L().ff_token_projmlp(ap, lda, xp, ldx, cp, ldc, _ptr(c2_scale), op_, ldo_, rows, K, m["ht"], pk["proj"]["w"].data_ptr(),
+                                     pk["proj"]["b"].data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), m["w"].data_ptr(),
+                                     m["b1"].data_ptr(), m["b2"].data_ptr(), _stream()))
+    _note(2.0 * rows * K * K + 4.0 * rows * K * m["ht"] * 32, 4.0 * rows * K * (3 + (c2 is not None)))
+    return out
+
+
 def token_linear(x: T, pk: dict, *, gamma: Optional[T] = None, beta: Optional[T] = None, eps: float = 1e-5, act=None,
                  res: Optional[T] = None, res2: Optional[T] = None, res2_scale: Optional[T] = None, want_xn: bool = False):
     """res + res2*scale + act(LayerNorm?(x) @ W^T + b) for K <= 192 in one launch (bf16x3); pk from prep.pack_token_linear.
@@ -755,7 +778,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "linear", "win_attn_fused", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
+for _n in ("conv2d", "linear", "win_attn_fused", "token_projmlp", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

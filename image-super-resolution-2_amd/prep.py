@@ -170,3 +170,25 @@ def pack_win_attn(wqkv: T, bqkv: Optional[T], heads: int, d: int, scale: float) 
                 bt[3 * g + j, :d] = bqkv[rows] * sc
     hi, lo = split_bf16(wt.reshape(3 * heads, 32 * 192))
     return dict(w=torch.stack([hi, lo], dim=1).contiguous(), b=bt.reshape(-1).contiguous(), heads=heads, d=d, K=K)
+
+
+def projmlp_k_perm() -> T:
+    """fc1 K-column order of ff_token_projmlp: operand position 16 st + 8 hh + j holds channel
+    32 (st >> 1) + 8 (2 (st & 1) + (j >> 2)) + 4 hh + (j & 3) -- the order in which the projection's accumulator registers
+    hold a token's channels (csrc/token_mlp.hip)."""
+    k = torch.arange(192)
+    st, hh, j = k // 16, (k % 16) // 8, k % 8
+    return 32 * (st // 2) + 8 * (2 * (st % 2) + j // 4) + 4 * hh + (j % 4)
+
+
+def pack_token_projmlp(wp: T, bp: T, w1: T, b1: T, w2: T, b2: T) -> dict:
+    """Weights of ff_token_projmlp: the projection in ff_token_linear's format, the MLP in ff_token_mlp's with fc1's columns
+    permuted (zero columns for the K padding)."""
+    hidden, K = w1.shape
+    assert K <= 192 and tuple(wp.shape) == (K, K)
+    w1p = torch.zeros(hidden, 192, device=w1.device)
+    w1p[:, :K] = w1
+    w1perm = w1p[:, projmlp_k_perm().to(w1.device)].contiguous()
+    mlp = pack_token_mlp(w1perm, b1, w2, b2)
+    mlp["K"] = K
+    return dict(proj=pack_token_linear(wp, bp), mlp=mlp)

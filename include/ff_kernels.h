@@ -83,6 +83,16 @@ int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_off, int v_
                          int shift_h, int shift_w, int use_mask, int heads, int d, float scale, int nterms, const float* rel_table,
                          void* stream);
 
+/* Attention output projection + residuals + norm2 + MLP in one launch (csrc/token_mlp.hip, token_projmlp_kernel):
+ *   x1 = x + proj(att) + c2 * c2_scale;  out = x1 + fc2(GELU(fc1(LayerNorm(x1))))        (hat_arch.py:303-307, OCAB :434-437)
+ * x1 never reaches memory.  proj_tiles / proj_bias_padded: ff_token_linear's weight format for the 180 -> 180 projection;
+ * mlp_tiles: ff_token_mlp's format with fc1's K columns in the accumulator-operand order (prep.pack_token_projmlp);
+ * c2 / c2_scale may be NULL (no convolution branch).  K = N <= 192, bf16x3. */
+int ff_token_projmlp(const float* att, int lda, const float* x, int ldx, const float* c2, int ldc, const float* c2_scale,
+                     float* out, int ldo, long long M, int K, int hidden_tiles, const void* proj_tiles,
+                     const float* proj_bias_padded, const float* gamma, const float* beta, float eps,
+                     const void* mlp_tiles, const float* b1_padded, const float* b2, void* stream);
+
 /* Window-resident attention block (csrc/win_attn_fused.hip): LayerNorm -> q/k/v projection -> softmax(q k^T + bias (+mask)) v
  * for ALL `nheads` heads of one 256-token window per workgroup; the qkv tensor never exists in memory.
  * Replaces, in one launch, HAB's norm1 + roll + window_partition + WindowAttention.forward up to the output projection

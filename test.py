@@ -42,6 +42,28 @@ def run(model_func, model_name, model_path, device, args, mode="test"):
     else:
         ms = (time.time() - t0) * 1e3
     print(f"Model {model_name} runtime (Including I/O): {ms} ms")
+    if getattr(args, "hr_dir", None):
+        evaluate(save_path, args.hr_dir, device)
+
+
+def evaluate(sr_dir, hr_dir, device, crop_border=4):
+    """PSNR-Y / SSIM-Y of the written outputs against ground-truth images, on the device (isr2_amd.metrics = the reference's
+    src/utils/metrics.py conventions: BT.601 luma, crop 4): only the two scalars per image leave the GPU."""
+    import glob
+    import numpy as np
+    from PIL import Image
+    from isr2_amd import metrics
+    ps, ss = [], []
+    for sr_path in sorted(glob.glob(os.path.join(sr_dir, "*.[pP][nN][gG]"))):
+        hr_path = os.path.join(hr_dir, os.path.basename(sr_path))
+        if not os.path.exists(hr_path):
+            continue
+        load = lambda p: torch.from_numpy(np.array(Image.open(p).convert("RGB"))).to(device).permute(2, 0, 1).float().div(255.0).unsqueeze(0)  # noqa: E731
+        p_, s_ = metrics.calculate_psnr_ssim_batch(load(sr_path), load(hr_path), crop_border, True)
+        ps.append(p_)
+        ss.append(s_)
+    if ps:
+        print(f"PSNR-Y {sum(ps) / len(ps):.4f} dB, SSIM-Y {sum(ss) / len(ss):.6f} over {len(ps)} images (crop {crop_border})")
 
 
 def main(args):
@@ -62,6 +84,7 @@ if __name__ == "__main__":
     parser.add_argument("--test_dir", default=None, type=str, help="Path to the test set")
     parser.add_argument("--save_dir", default="NTIRE2026-ImageSRx4/results", type=str)
     parser.add_argument("--model_id", default=29, type=int)
+    parser.add_argument("--hr_dir", default=None, type=str, help="optional ground-truth directory: report PSNR-Y / SSIM-Y (device evaluator)")
     args = parser.parse_args()
     pprint(args)
     main(args)

@@ -710,3 +710,27 @@ def test_win_attn_fused_dat_branches(dev, H, W, shifted):
         close(vout[..., 2 * C:], qkv[..., 2 * C:], GEMM_TOL["bf16x3"], "v side output")
     finally:
         ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("M,with_conv", [(65536, True), (1000, True), (77, False), (4096, False)])
+def test_token_projmlp_fused(dev, M, with_conv):
+    """proj + shortcut + conv_x * scale + norm2 + MLP in one launch (hat_arch.py:303-307) against the PyTorch fp32 chain."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_token_projmlp
+    C, Hd = 180, 360
+    att = torch.empty(M, 192, device=dev)[:, :C]
+    att.copy_(rnd(M, C, dev=dev, seed=400))
+    x = torch.empty(M, 192, device=dev)[:, :C]
+    x.copy_(rnd(M, C, dev=dev, seed=401, scale=1.5) + 0.3)
+    c2 = torch.empty(M, 192, device=dev)[:, :C]
+    c2.copy_(rnd(M, C, dev=dev, seed=402))
+    scale = (rnd(C, dev=dev, seed=403).abs() * 0.01).contiguous()
+    g, b = rnd(C, dev=dev, seed=404) * 0.1 + 1, rnd(C, dev=dev, seed=405) * 0.1
+    wp, bp = rnd(C, C, dev=dev, seed=406, scale=1.0 / math.sqrt(C)), rnd(C, dev=dev, seed=407, scale=0.1)
+    w1, b1 = rnd(Hd, C, dev=dev, seed=408, scale=1.0 / math.sqrt(C)), rnd(Hd, dev=dev, seed=409, scale=0.1)
+    w2, b2 = rnd(C, Hd, dev=dev, seed=410, scale=1.0 / math.sqrt(Hd)), rnd(C, dev=dev, seed=411, scale=0.1)
+    x1 = x + F.linear(att, wp, bp) + (c2 * scale if with_conv else 0.0)
+    ref = x1 + F.linear(F.gelu(F.linear(F.layer_norm(x1, (C,), g, b, 1e-5), w1, b1)), w2, b2)
+    pk = pack_token_projmlp(wp, bp, w1, b1, w2, b2)
+    out = ops.token_projmlp(att, x, pk, g, b, c2=c2 if with_conv else None, c2_scale=scale if with_conv else None)
+    close(out, ref, 6e-5, "token_projmlp")
