@@ -97,10 +97,90 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(DwParams p) {
       acc = (acc + bias) * ps + pt;
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = ff_act_c<ACT, false>(acc[e]) * mul[r][e];
+      // GELU through the 1.5e-7-accurate erf of ff_gelu_fast: the libm erff costs ~55 VALU ops with divergent branches and made
+      // this HBM-bound kernel VALU-bound (66 us for 94 MB at 65 536 x 180; r2)
+      for (int e = 0; e < 4; ++e) o[e] = ff_act_c<ACT, true>(acc[e]) * mul[r][e];
       *reinterpret_cast<f32x4*>(p.out + ((long long)(b * p.H + y0 + r) * p.W + ox) * p.ldo + c) = o;
     }
   }
+}
+
+// The same strip kernel with LayerNorm applied ON LOAD (DAT SpatialGate, dat_arch.py:117-122: x2 -> LayerNorm -> dw3x3, times x1):
+// the per-token (mean, rstd) come from the producer's epilogue (ff_token_linear stats_out), gamma / beta per channel; the
+// convolution's zero padding applies to the NORMALISED tensor, so out-of-image taps contribute exactly zero.
+struct DwLnParams {
+  const float* in; float* out; const float* w; const float* bias; const float* stats; const float* gamma; const float* beta;
+  const float* mulin;
+  int ldm, ldi, ldo, B, H, W, C;
+};
+
+__global__ __launch_bounds__(256) void dwconv3x3_ln_strip_kernel(DwLnParams p) {
+  const int c4n = p.C >> 2;
+  const int nstrip = (p.H + 3) >> 2;
+  const long long total = (long long)p.B * nstrip * p.W * c4n;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % c4n) * 4;
+    long long t = idx / c4n;
+    const int ox = (int)(t % p.W); t /= p.W;
+    const int y0 = (int)(t % nstrip) * 4;
+    const int b = (int)(t / nstrip);
+    f32x4 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f32x4*>(p.w + (long long)k * p.C + c);
+    const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : z4;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c), b4 = *reinterpret_cast<const f32x4*>(p.beta + c);
+    f32x4 in[6][3];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int iy = y0 - 1 + r;
+      const bool oky = (unsigned)iy < (unsigned)p.H;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int ix = ox - 1 + k;
+        const bool ok = oky && (unsigned)ix < (unsigned)p.W;
+        const long long tk = ok ? (long long)(b * p.H + iy) * p.W + ix : 0;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p.in + tk * p.ldi + c);
+        const float2 ms = *reinterpret_cast<const float2*>(p.stats + 2 * tk);
+        in[r][k] = ok ? (u - ms.x) * ms.y * g4 + b4 : z4;
+      }
+    }
+    f32x4 mul[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = p.mulin && y0 + r < p.H;
+      mul[r] = ok ? *reinterpret_cast<const f32x4*>(p.mulin + ((long long)(b * p.H + y0 + r) * p.W + ox) * p.ldm + c) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (y0 + r >= p.H) break;
+      f32x4 acc = z4;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc += in[r + ky][kx] * w[ky * 3 + kx];
+      *reinterpret_cast<f32x4*>(p.out + ((long long)(b * p.H + y0 + r) * p.W + ox) * p.ldo + c) = (acc + bias) * mul[r];
+    }
+  }
+}
+
+extern "C" int ff_dwconv3x3_ln(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, const float* w_tapmajor,
+                               const float* bias, const float* stats, const float* gamma, const float* beta, const float* mul_in,
+                               int ldm, void* stream) {
+  FF_CHECK_ARG(in && out && w_tapmajor && stats && gamma && beta && in != out, "ff_dwconv3x3_ln: null pointer / in-place");
+  FF_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldi >= C && ldo >= C && ldi % 4 == 0 && ldo % 4 == 0, "ff_dwconv3x3_ln: bad dims");
+  FF_CHECK_ARG((((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)w_tapmajor) & 15) == 0 && (((uintptr_t)gamma) & 15) == 0 &&
+               (((uintptr_t)beta) & 15) == 0 && (((uintptr_t)stats) & 7) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0), "ff_dwconv3x3_ln: alignment");
+  FF_CHECK_ARG(!mul_in || (ldm >= C && ldm % 4 == 0 && (((uintptr_t)mul_in) & 15) == 0), "ff_dwconv3x3_ln: mul_in rows must be 16-byte aligned");
+  DwLnParams p;
+  p.in = in; p.out = out; p.w = w_tapmajor; p.bias = bias; p.stats = stats; p.gamma = gamma; p.beta = beta; p.mulin = mul_in;
+  p.ldm = ldm; p.ldi = ldi; p.ldo = ldo; p.B = B; p.H = H; p.W = W; p.C = C;
+  const long long tot = (long long)B * ((H + 3) / 4) * W * (C / 4);
+  long long nbs = (tot + 255) / 256;
+  if (nbs > 256 * 32) nbs = 256 * 32;
+  hipLaunchKernelGGL(dwconv3x3_ln_strip_kernel, dim3((unsigned)nbs), dim3(256), 0, (hipStream_t)stream, p);
+  FF_LAUNCH_CHECK("ff_dwconv3x3_ln");
+  return FF_OK;
 }
 
 __global__ __launch_bounds__(256) void dwconv_scalar_kernel(DwParams p) {

@@ -23,6 +23,7 @@ struct TokenLinParams {
   const float* bias;                       // [NT*32] zero padded (or NULL)
   const float* res; const float* res2; const float* rs2;
   float* xn; int ldxn;                     // optional side output: the LayerNorm'ed rows (NULL: not written)
+  float* stats; int st_lo, st_hi; float st_eps;   // optional side output: per token (mean, rstd) of OUTPUT channels [st_lo, st_hi)
   long long M;
   int ldx, ldo, ldr, ldr2, K, N, NT, act;
   float eps;
@@ -121,6 +122,10 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
     }
   }
 
+  // LayerNorm statistics of a channel range of the (activated) OUTPUT, taken from the accumulators on their way out: the
+  // consumer (DAT's SpatialGate: LayerNorm -> depth-wise 3x3, dat_arch.py:117-122) normalises on load, so the separate
+  // LayerNorm pass over the 360-channel half (read 94 MB, write 94 MB) disappears
+  float ssum = 0.f, ssq = 0.f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile 0 (this wave's DMA pieces) landed
   for (int nt = 0; nt < p.NT; ++nt) {
     const int buf = nt & 1;
@@ -198,6 +203,12 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v4[e] = ff_act_c<ACT, true>(acc[4 * g + e]);
       *reinterpret_cast<f32x4*>(tr + l31 * TL_TR + 8 * g + 4 * hh) = v4;
+      if (p.stats) {
+        const int c0 = nt * 32 + 8 * g + 4 * hh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c0 + e >= p.st_lo && c0 + e < p.st_hi) { ssum += v4[e]; ssq += v4[e] * v4[e]; }
+      }
     }
     // One wait per tile, placed BEFORE this tile's stores: it retires the DMA of tile nt+1 (issued a whole tile ago),
     // this tile's residual loads and the PREVIOUS tile's stores -- so stores always have a full tile to drain
@@ -235,12 +246,22 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
       }
     }
   }
+  if (p.stats) {
+    ssum += __shfl_xor(ssum, 32);
+    ssq += __shfl_xor(ssq, 32);
+    const float n = (float)(p.st_hi - p.st_lo);
+    const float mean = ssum / n;
+    const float var = fmaxf(ssq / n - mean * mean, 0.f);
+    if (hh == 0 && tvalid) *reinterpret_cast<float2*>(p.stats + 2 * tok) = make_float2(mean, 1.0f / sqrtf(var + p.st_eps));
+  }
 }
+
 
 extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, int K, int kpad, int N, int n_tiles,
                                const float* gamma, const float* beta, float eps, const void* w_tiles,
                                const float* bias_padded, int act, const float* res, int ldr, const float* res2, int ldr2,
-                               const float* res2_scale, float* xn_out, int ldxn, void* stream) {
+                               const float* res2_scale, float* xn_out, int ldxn, float* stats_out, int stat_lo, int stat_hi,
+                               float stat_eps, void* stream) {
   FF_CHECK_ARG(x && out && w_tiles, "ff_token_linear: null pointer");
   FF_CHECK_ARG(M > 0 && K > 0 && K <= 192 && K % 4 == 0 && N > 0 && n_tiles * 32 >= N, "ff_token_linear: needs K <= 192 (K %% 4 == 0), n_tiles*32 >= N");
   FF_CHECK_ARG(kpad == 64 || kpad == 128 || kpad == 192, "ff_token_linear: kpad must be 64, 128 or 192");
@@ -255,6 +276,8 @@ extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, lon
   p.x = x; p.out = out; p.gamma = gamma; p.beta = beta; p.w = (const __bf16*)w_tiles; p.bias = bias_padded;
   p.res = res; p.res2 = res2; p.rs2 = res2_scale; p.xn = xn_out; p.ldxn = ldxn; p.M = M; p.ldx = ldx; p.ldo = ldo; p.ldr = ldr; p.ldr2 = ldr2;
   p.K = K; p.N = N; p.NT = n_tiles; p.act = act; p.eps = eps;
+  FF_CHECK_ARG(!stats_out || (stat_lo >= 0 && stat_hi > stat_lo && stat_hi <= N && (((uintptr_t)stats_out) & 7) == 0), "ff_token_linear: bad statistics range");
+  p.stats = stats_out; p.st_lo = stat_lo; p.st_hi = stat_hi; p.st_eps = stat_eps;
   const bool vec4 = (N % 4 == 0) && (ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && (!res || (ldr % 4 == 0 && (((uintptr_t)res) & 15) == 0)) &&
            (!res2 || (ldr2 % 4 == 0 && (((uintptr_t)res2) & 15) == 0 && (((uintptr_t)res2_scale) & 15) == 0));
   const int ks = kpad / 16;

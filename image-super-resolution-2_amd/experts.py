@@ -61,6 +61,9 @@ def _fast() -> bool:
 _WIN_FUSED = os.environ.get("FF_WIN_FUSED", "1") != "0"
 # Attention projection + residuals + norm2 + MLP in one launch (csrc/token_mlp.hip: token_projmlp_kernel); 0 = two launches
 _PROJ_MLP = os.environ.get("FF_PROJ_MLP", "1") != "0"
+# DAT SpatialGate: LayerNorm statistics from the fc1 epilogue, normalisation on load in the depth-wise conv: 101 us against
+# 45 + 72 us for the separate LayerNorm pass + plain strip kernel (tools/block_timeline.py).  FF_LN_ON_LOAD=0 restores those.
+_LN_ON_LOAD = os.environ.get("FF_LN_ON_LOAD", "1") != "0"
 
 
 def _pm(blk: dict) -> dict:
@@ -389,6 +392,12 @@ class DatHIP:
             fused = ops.mix2(att, conv_x, pa=sm, cb=cm)
         x = ops.token_linear(fused, _tl(blk, "proj"), res=x) if _fast() else ops.linear(fused, *blk["proj"], res=x)
         # SGFN
+        if _fast() and _LN_ON_LOAD:
+            # fc1 + GELU also emits the SpatialGate LayerNorm statistics of its upper half; the depth-wise conv normalises on load
+            c2 = blk["fc1"][0].shape[0] // 2
+            y, stats = ops.token_linear(x, _tl(blk, "fc1"), gamma=blk["n2"][0], beta=blk["n2"][1], act="gelu", stats_range=(c2, 2 * c2))
+            z = ops.dwconv3x3_ln(y[..., c2:], blk["sgc"][0], blk["sgc"][1], stats, blk["sgn"][0], blk["sgn"][1], mul_in=y[..., :c2])
+            return ops.linear(z, *blk["fc2"], res=x)
         if _fast():
             y = ops.token_linear(x, _tl(blk, "fc1"), gamma=blk["n2"][0], beta=blk["n2"][1], act="gelu")
         else:

@@ -386,9 +386,11 @@ def token_projmlp(att: T, x: T, pk: dict, gamma: T, beta: T, *, c2: Optional[T] 
 
 
 def token_linear(x: T, pk: dict, *, gamma: Optional[T] = None, beta: Optional[T] = None, eps: float = 1e-5, act=None,
-                 res: Optional[T] = None, res2: Optional[T] = None, res2_scale: Optional[T] = None, want_xn: bool = False):
+                 res: Optional[T] = None, res2: Optional[T] = None, res2_scale: Optional[T] = None, want_xn: bool = False,
+                 stats_range: Optional[Tuple[int, int]] = None, stats_eps: float = 1e-5):
     """res + res2*scale + act(LayerNorm?(x) @ W^T + b) for K <= 192 in one launch (bf16x3); pk from prep.pack_token_linear.
-    want_xn: also return LayerNorm(x) (written by the same launch) -> (out, xn)."""
+    want_xn: also return LayerNorm(x) (written by the same launch) -> (out, xn).
+    stats_range=(lo, hi): also return [rows, 2] (mean, rstd) of the activated output channels [lo, hi) -> (out, stats)."""
     xp, ldx, rows, K = rows_view(x, "token_linear.x")
     if K != pk["K"]:
         raise _lib.FFError("token_linear: K mismatch")
@@ -412,10 +414,17 @@ def token_linear(x: T, pk: dict, *, gamma: Optional[T] = None, beta: Optional[T]
             raise _lib.FFError("token_linear: want_xn needs LayerNorm parameters")
         xn = empty_like_rows(x)
         xnp, ldxn, _, _ = rows_view(xn, "token_linear.xn")
+    stats, sp, slo, shi = None, None, 0, 0
+    if stats_range is not None:
+        slo, shi = stats_range
+        stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+        sp = stats.data_ptr()
     _lib.check(_L().ff_token_linear(xp, ldx, out.data_ptr(), ldo, rows, K, pk["kpad"], N, pk["nt"], _ptr(gamma), _ptr(beta), float(eps),
                                     pk["w"].data_ptr(), _ptr(pk["b"]), ACT[act], rp, ldr, r2p, ldr2, _ptr(res2_scale), xnp, ldxn,
-                                    _stream()))
+                                    sp, slo, shi, float(stats_eps), _stream()))
     _note(2.0 * rows * N * K, 4.0 * (rows * K * (2 if want_xn else 1) + rows * N * (1 + (res is not None) + (res2 is not None))))
+    if stats is not None:
+        return out, stats
     return (out, xn) if want_xn else out
 
 
@@ -517,6 +526,24 @@ def dwconv2d(x: T, w_tap: T, bias: Optional[T] = None, *, ksize=(3, 3), stride=(
     _lib.check(_L().ff_dwconv2d(xp, ldi, op, ldo, B, H, W, C, Ho, Wo, w_tap.data_ptr(), _ptr(bias), KH, KW, stride[0],
                                 stride[1], pad[0], pad[1], _ptr(post_scale), _ptr(post_shift), ACT[act], mp, ldm, _stream()))
     _note(2.0 * B * Ho * Wo * C * KH * KW, 4.0 * (B * H * W * C + B * Ho * Wo * C))
+    return out
+
+
+def dwconv3x3_ln(x: T, w_tap: T, bias: Optional[T], stats: T, gamma: T, beta: T, mul_in: Optional[T] = None) -> T:
+    """(dw3x3(LayerNorm(x)) + bias) * mul_in with the LayerNorm applied on load from per-token (mean, rstd) `stats`."""
+    xp, ldi, B, H, W, C = _nhwc(x, "dwconv3x3_ln.x")
+    if tuple(w_tap.shape) != (9, C) or tuple(stats.shape) != (B * H * W, 2) or gamma.numel() != C or beta.numel() != C:
+        raise _lib.FFError("dwconv3x3_ln: shape mismatch")
+    out = empty_rows((B, H, W, C), x.device)
+    op, ldo, *_ = _nhwc(out, "dwconv3x3_ln.out")
+    mp, ldm = None, 0
+    if mul_in is not None:
+        mp, ldm, mb, mh, mw, mc = _nhwc(mul_in, "dwconv3x3_ln.mul_in")
+        if (mb, mh, mw, mc) != (B, H, W, C):
+            raise _lib.FFError("dwconv3x3_ln: mul_in shape mismatch")
+    _lib.check(_L().ff_dwconv3x3_ln(xp, ldi, op, ldo, B, H, W, C, w_tap.data_ptr(), _ptr(bias), stats.data_ptr(), gamma.data_ptr(),
+                                    beta.data_ptr(), mp, ldm, _stream()))
+    _note(2.0 * B * H * W * C * 9, 4.0 * B * H * W * C * (3 if mul_in is not None else 2))
     return out
 
 
@@ -778,7 +805,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "linear", "win_attn_fused", "token_projmlp", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "mix2", "fma3", "affine",
+for _n in ("conv2d", "linear", "win_attn_fused", "token_projmlp", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

@@ -149,11 +149,13 @@ int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const f
  * kpad = K rounded up to 64 / 128 / 192.  w_tiles: bf16 [n_tiles][2][32][kpad] (hi, lo planes; rows >= N and cols >= K
  * zero) from prep.pack_token_linear;
  * bias zero padded to n_tiles*32 (or NULL).  xn_out (optional, needs gamma): the LayerNorm'ed rows are also written there
- * (row pitch ldxn), which saves the separate ff_layernorm pass when another consumer needs them (HAT's CAB branch). */
+ * (row pitch ldxn), which saves the separate ff_layernorm pass when another consumer needs them (HAT's CAB branch).  * stats_out (optional) [M][2]: per token (mean, 1/sqrt(var + stat_eps)) of the activated OUTPUT channels [stat_lo, stat_hi) -- the
+ * LayerNorm statistics a consumer applies on load (ff_dwconv3x3_ln; DAT SpatialGate, dat_arch.py:117-122). */
 int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, int K, int kpad, int N, int n_tiles,
                     const float* gamma, const float* beta, float eps, const void* w_tiles, const float* bias_padded,
                     int act, const float* res, int ldr, const float* res2, int ldr2, const float* res2_scale,
-                    float* xn_out, int ldxn, void* stream);
+                    float* xn_out, int ldxn, float* stats_out, int stat_lo,
+                    int stat_hi, float stat_eps, void* stream);
 
 /* NAFNet block fusions (csrc/naf_fused.hip).
  * ff_dwconv3_gate_pool: out[p][c] = dw3x3(in)[p][c] * dw3x3(in)[p][C + c] (conv2 + SimpleGate, nafnet_arch.py:78-81,51-52)
@@ -189,6 +191,14 @@ int ff_vec_mlp(const float* in, int B, int Cin, const float* W1, const float* b1
 int ff_dwconv2d(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, int Ho, int Wo,
                 const float* w_tapmajor, const float* bias, int KH, int KW, int sy, int sx, int py, int px,
                 const float* post_scale, const float* post_shift, int act, const float* mul_in, int ldm, void* stream);
+
+/* Depth-wise 3x3 / stride 1 / pad 1 with LayerNorm applied on load (csrc/dwconv.hip):
+ *   out = (dw3x3( gamma * (in - mean[token]) * rstd[token] + beta ) + bias) * mul_in        zero padding AFTER the normalisation
+ * stats [tokens][2] = (mean, rstd) per token from ff_token_linear's stats_out.  Replaces SpatialGate.forward's
+ * norm + conv + gate product (dat_arch.py:117-123) without a separate LayerNorm pass. */
+int ff_dwconv3x3_ln(const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, const float* w_tapmajor,
+                    const float* bias, const float* stats, const float* gamma, const float* beta, const float* mul_in, int ldm,
+                    void* stream);
 
 /* out = ka*a*ca[c]*pa[p] + kb*b*cb[c]*pb[p]   (b, ca, cb, pa, pb may be NULL; clamp01 clamps to [0,1]) */
 int ff_mix2(float* out, int ldo, const float* a, int lda, const float* b, int ldb, long long rows, int C, float ka,

@@ -734,3 +734,31 @@ def test_token_projmlp_fused(dev, M, with_conv):
     pk = pack_token_projmlp(wp, bp, w1, b1, w2, b2)
     out = ops.token_projmlp(att, x, pk, g, b, c2=c2 if with_conv else None, c2_scale=scale if with_conv else None)
     close(out, ref, 6e-5, "token_projmlp")
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (37, 45)])
+def test_sgfn_layernorm_on_load(dev, H, W):
+    """DAT SGFN first half (dat_arch.py:163-166 fc1 + GELU, :117-123 SpatialGate): ff_token_linear's LayerNorm statistics side
+    output + ff_dwconv3x3_ln (normalise on load, zero padding after the normalisation) against the PyTorch fp32 chain."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_token_linear, pack_dw
+    C, Hd = 180, 720
+    M = H * W
+    x = torch.empty(1, H, W, 192, device=dev)[..., :C]
+    x.copy_(rnd(1, H, W, C, dev=dev, seed=500, scale=1.5) + 0.3)
+    g, b = rnd(C, dev=dev, seed=501) * 0.1 + 1, rnd(C, dev=dev, seed=502) * 0.1
+    w1, b1 = rnd(Hd, C, dev=dev, seed=503, scale=1.0 / math.sqrt(C)), rnd(Hd, dev=dev, seed=504, scale=0.1)
+    g2, bb2 = rnd(Hd // 2, dev=dev, seed=505) * 0.1 + 1, rnd(Hd // 2, dev=dev, seed=506) * 0.1
+    wd, bd = rnd(Hd // 2, 1, 3, 3, dev=dev, seed=507, scale=0.3), rnd(Hd // 2, dev=dev, seed=508, scale=0.1)
+    y_ref = F.gelu(F.linear(F.layer_norm(x, (C,), g, b, 1e-5), w1, b1))
+    x1, x2 = y_ref[..., :Hd // 2], y_ref[..., Hd // 2:]
+    x2n = F.layer_norm(x2, (Hd // 2,), g2, bb2, 1e-5).permute(0, 3, 1, 2)
+    ref = x1 * F.conv2d(x2n, wd, bd, padding=1, groups=Hd // 2).permute(0, 2, 3, 1)
+    y, stats = ops.token_linear(x, pack_token_linear(w1, b1), gamma=g, beta=b, act="gelu", stats_range=(Hd // 2, Hd))
+    close(y, y_ref, 6e-5, "fc1 + gelu")
+    mean_ref = x2.mean(-1).reshape(M)
+    rstd_ref = 1.0 / torch.sqrt(x2.var(-1, unbiased=False).reshape(M) + 1e-5)
+    close(stats[:, 0], mean_ref, 3e-5, "token mean")
+    assert ((stats[:, 1] - rstd_ref).abs() / rstd_ref).max().item() < 2e-4
+    z = ops.dwconv3x3_ln(y[..., Hd // 2:], pack_dw(wd), bd, stats, g2, bb2, mul_in=y[..., :Hd // 2])
+    close(z, ref, 1e-4, "SpatialGate with LayerNorm on load")
