@@ -347,6 +347,8 @@ def main():
                                       "compulsory = fp32 weights read once + LR in + SR out"}
         roof["other_kernels"] = [r for r in (
             _fam("token_linear", "hbm", 8000.0, "GB/s", "token_linear_all_variants"),
+            _fam("win_attn_fused", "mfma", peak, "TFLOP/s", "win_attn_fused_all_variants"),
+            _fam("token_projmlp", "mfma", peak, "TFLOP/s", "token_projmlp"),
             _fam("window_attn", "mfma", peak, "TFLOP/s", "window_attn_all_variants"),
             _fam("token_mlp", "mfma", peak, "TFLOP/s", "token_mlp")) if r]
         breakdown = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / max(v[1], 1e-9) / 1e9, 2),

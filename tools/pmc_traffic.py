@@ -59,10 +59,13 @@ def main():
            "conv_igemm_all_variants": family(lambda k: "conv_igemm" in k or "conv3x3_halo" in k),
            "token_linear_all_variants": family(lambda k: "token_linear" in k),
            "window_attn_all_variants": family(lambda k: "window_attn" in k),
+           "win_attn_fused_all_variants": family(lambda k: "win_attn_fused" in k),
            "token_mlp": family(lambda k: "token_mlp" in k),
+           "token_projmlp": family(lambda k: "token_projmlp" in k),
            "whole_forward": family(lambda k: True)}
     json.dump(doc, open(out, "w"), indent=1)
-    for k in ("conv_igemm_all_variants", "token_linear_all_variants", "window_attn_all_variants", "token_mlp", "whole_forward"):
+    for k in ("conv_igemm_all_variants", "token_linear_all_variants", "window_attn_all_variants", "win_attn_fused_all_variants", "token_mlp",
+              "token_projmlp", "whole_forward"):
         print(k, doc[k])
 
 
