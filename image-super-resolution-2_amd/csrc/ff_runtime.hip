@@ -13,7 +13,9 @@ void ff_set_error(const char* fmt, ...) {
 
 extern "C" const char* ff_last_error(void) { return g_err; }
 
-extern "C" int ff_abi_version(void) { return 1; }
+// 2: ff_token_linear gained the statistics side output; ff_win_attn_fused, ff_token_projmlp, ff_dwconv3x3_ln, the metric and
+// executor entry points were added (round 2)
+extern "C" int ff_abi_version(void) { return 2; }
 
 // Number of compute units of the current device (bench.py sizes its roofline report with it).
 extern "C" int ff_device_cu_count(void) {

@@ -281,6 +281,29 @@ int ff_psnr_mse(const float* a, const float* b, int C, int H, int W, int crop, i
 int ff_ssim_mean(const float* a, const float* b, int C, int H, int W, int crop, int use_y, const float* gauss11, double* work,
                  int nwork, double* out_ssim, void* stream);
 
+/* C-level executor (csrc/ff_executor.hip): the whole forward -- models/team29_FreqFusion/io.py:221 `model(lr)` =
+ * CompleteEnhancedFusionSR.forward, src/models/enhanced_fusion.py:694-754 -- for callers without Python.  A plan
+ * (<stem>.ffplan, written by isr2_amd.plan.export_plan) lists every launch of one input shape with pointers expressed as
+ * (prepared-weight slot | workspace | input | output, offset); <stem>.ffwts carries the prepared weights.
+ *   ff_create    load a plan on the CURRENT device; allocates the weight slots and the workspace (the library owns both)
+ *   ff_upload    copy `nbytes` from a host or device buffer into the named slot (sizes must match the plan)
+ *   ff_finalize  succeeds once every slot has been uploaded
+ *   ff_forward   lr_dev [B,3,H,W] fp32 -> out_dev [B,3,4H,4W]; all launches go to `stream` in plan order (asynchronous,
+ *                graph-capturable); B, H, W must be the plan's
+ *   ff_destroy   frees everything the handle owns
+ * Handles are not thread-safe; use one per host thread (kernels of different handles may run on different streams). */
+int ff_create(const char* plan_path, void** out_handle);
+int ff_upload(void* handle, const char* slot_name, const void* host_or_dev_ptr, long long nbytes);
+int ff_finalize(void* handle);
+int ff_forward(void* handle, const float* lr_dev, int B, int H, int W, float* out_dev, void* stream);
+int ff_destroy(void* handle);
+int ff_model_io_shape(void* handle, int* in_shape4, int* out_shape4);
+int ff_model_num_slots(void* handle);
+const char* ff_model_slot_name(void* handle, int i);
+long long ff_model_slot_bytes(void* handle, int i);
+long long ff_model_workspace_bytes(void* handle);
+int ff_model_num_launches(void* handle);
+
 #ifdef __cplusplus
 }
 #endif
