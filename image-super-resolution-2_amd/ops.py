@@ -278,44 +278,6 @@ def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] =
     return out
 
 
-def split_rows(x: T, Kp: Optional[int] = None) -> Tuple[T, T]:
-    """fp32 rows [..., K] -> bf16 planes (hi, lo) [rows, Kp]."""
-    xp, ld, rows, K = rows_view(x, "split_rows.x")
-    Kp = Kp or (K + 31) // 32 * 32
-    hi = torch.empty((rows, Kp), device=x.device, dtype=torch.bfloat16)
-    lo = torch.empty((rows, Kp), device=x.device, dtype=torch.bfloat16)
-    _lib.check(_L().ff_split_rows(xp, ld, rows, K, Kp, hi.data_ptr(), lo.data_ptr(), _stream()))
-    _note(0.0, 8.0 * rows * K)
-    return hi, lo
-
-
-def gemm_planes(a: Tuple[T, T], w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] = None, mul: Optional[T] = None,
-                alpha: float = 1.0, out: Optional[T] = None, dynamic_w: bool = False, oshape=None) -> T:
-    """a = (hi, lo) bf16 planes [M, Kp] of the activations, w fp32 [N, K] -> [M, N] (or oshape) fp32."""
-    ah, al = a
-    M, Kp = ah.shape
-    N, K = w.shape
-    hi, lo, wKp, _, _ = _split_weight(w, dynamic_w, 0)
-    if wKp != Kp:
-        raise _lib.FFError(f"gemm_planes: activation planes have Kp = {Kp}, weights {wKp}")
-    if out is None:
-        out = torch.empty(tuple(oshape) if oshape is not None else (M, N), device=ah.device, dtype=torch.float32)
-    op, ldo, orows, oc = rows_view(out, "gemm_planes.out")
-    if orows != M or oc != N:
-        raise _lib.FFError("gemm_planes: out shape mismatch")
-    rp, ldr = None, 0
-    if res is not None:
-        rp, ldr, rrows, rc = rows_view(res, "gemm_planes.res")
-        if rrows != M or rc != N:
-            raise _lib.FFError("gemm_planes: res shape mismatch")
-    nt = 1 if _GEMM_MODE == "bf16" else 3
-    _lib.check(_L().ff_gemm_planes(ah.data_ptr(), al.data_ptr() if al is not None else None, hi.data_ptr(),
-                                   lo.data_ptr() if lo is not None else None, M, N, Kp, _ptr(bias), _ptr(mul), rp, ldr, op, ldo,
-                                   ACT[act], float(alpha), nt, _stream()))
-    _note(2.0 * M * N * K, 4.0 * (M * K + N * K + M * N * (2 if res is not None else 1)))
-    return out
-
-
 def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int, o_off: int, H: int, W: int, Hp: int,
                 Wp: int, win: Tuple[int, int], kwin: Tuple[int, int], shift: Tuple[int, int], use_mask: bool, heads: int,
                 d: int, scale: float, rel_table: Optional[T] = None) -> T:
@@ -843,7 +805,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "linear", "gemm_planes", "split_rows", "win_attn_fused", "token_projmlp", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
+for _n in ("conv2d", "linear", "win_attn_fused", "token_projmlp", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

@@ -57,15 +57,6 @@ int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_lo, int Kp,
                     int nterms, int tile_hint, void* stream);
 int ff_split_bf16(const float* w, int N, int K, int Kp, int Cin, int Cp, void* hi, void* lo, void* stream);
 
-/* GEMM on pre-split bf16 planes (csrc/gemm_planes.hip): out[m][n] = res + alpha * mul[n] * act(sum_k A[m][k] B[n][k] + bias[n]),
- * A = a_hi + a_lo [M][Kp], B = b_hi + b_lo [N][Kp] (Kp % 32 == 0, zero padded; B from ff_split_bf16 with the flat layout, A from
- * the producer kernel or ff_split_rows).  Both operand tiles stream by LDS-DMA; no conversion in the K loop.  N % 4 == 0.
- * Replaces the 1x1 convolutions with K >= 256 (nafnet_arch.py:77,82,95,96 at 256 / 512 / 1024 channels). nterms 3 or 1. */
-int ff_gemm_planes(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, int M, int N, int Kp,
-                   const float* bias, const float* mul, const float* res, int ldr, float* out, int ldo, int act, float alpha,
-                   int nterms, void* stream);
-/* fp32 rows [M][ld] (K channels) -> bf16 planes hi / lo [M][Kp] (lo may be NULL). */
-int ff_split_rows(const float* x, int ld, long long M, int K, int Kp, void* hi, void* lo, void* stream);
 
 /* Fused window attention softmax((q*scale) k^T + bias (+mask)) v on fp32 MFMA; one workgroup per
  * (window, head).  qkv is the token tensor [B][H][W][ldq]; q/k/v of head h live at *_off + h*d.

@@ -762,26 +762,3 @@ def test_sgfn_layernorm_on_load(dev, H, W):
     assert ((stats[:, 1] - rstd_ref).abs() / rstd_ref).max().item() < 2e-4
     z = ops.dwconv3x3_ln(y[..., Hd // 2:], pack_dw(wd), bd, stats, g2, bb2, mul_in=y[..., :Hd // 2])
     close(z, ref, 1e-4, "SpatialGate with LayerNorm on load")
-
-
-@pytest.mark.parametrize("M,K,N", [(4096, 1024, 2048), (4096, 1024, 1024), (16384, 512, 1024), (65536, 256, 512), (1000, 256, 260), (77, 512, 128)])
-def test_gemm_planes_matches_torch(dev, M, K, N):
-    """ff_gemm_planes (both operands as bf16 hi/lo planes, LDS-DMA ring) against torch fp32 at NAFNet's deep-level shapes
-    (nafnet_arch.py:77,82,95,96 at c = 256 / 512 / 1024) and ragged M / N."""
-    from isr2_amd import ops
-    prev = ops.gemm_mode()
-    ops.set_gemm_mode("bf16x3")
-    try:
-        x = rnd(M, K, dev=dev, seed=600)
-        w = rnd(N, K, dev=dev, seed=601, scale=1.0 / math.sqrt(K))
-        b = rnd(N, dev=dev, seed=602, scale=0.1)
-        mul = rnd(N, dev=dev, seed=603)
-        res = rnd(M, N, dev=dev, seed=604)
-        ref = res + 0.5 * mul * F.gelu(F.linear(x, w, b))
-        planes = ops.split_rows(x)
-        assert torch.equal(planes[0].float() + planes[1].float(), (planes[0].float() + planes[1].float()))
-        close(planes[0].float() + planes[1].float(), x, 2e-5, "hi + lo planes")
-        out = ops.gemm_planes(planes, w, b, act="gelu", res=res, mul=mul, alpha=0.5)
-        close(out, ref, GEMM_TOL["bf16x3"], "gemm_planes")
-    finally:
-        ops.set_gemm_mode(prev)
