@@ -119,6 +119,18 @@ extern "C" int ff_chan_attn_weights(const float* qkv, int ld, int q_off, int k_o
   return FF_OK;
 }
 
+// reduce + normalise + softmax of per-workgroup partials already in `work` (written by ff_chan_qkv: nblk blocks of 5760 floats)
+extern "C" int ff_chan_attn_finish(float* work, long long work_floats, int nblk, const float* temperature, float* wbd, void* stream) {
+  FF_CHECK_ARG(work && temperature && wbd && nblk > 0, "ff_chan_attn_finish: bad args");
+  FF_CHECK_ARG(work_floats >= (long long)(nblk + 1) * 5760, "ff_chan_attn_finish: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* G = work + (long long)nblk * 5760;
+  hipLaunchKernelGGL(chan_reduce_kernel, dim3((5760 + 255) / 256), dim3(256), 0, st, work, nblk, G);
+  hipLaunchKernelGGL(chan_attn_weights_kernel, dim3(180), dim3(64), 0, st, G, temperature, wbd);
+  FF_LAUNCH_CHECK("ff_chan_attn_finish");
+  return FF_OK;
+}
+
 extern "C" long long ff_chan_attn_workspace(long long N) {
   long long nblk = (N + 255) / 256;
   if (nblk > 1024) nblk = 1024;

@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from .prep import (pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv, pack_token_mlp, pack_token_linear, pack_naf_ffn,
-                   pack_win_attn, pack_win_rel, pack_token_projmlp)
+                   pack_win_attn, pack_win_rel, pack_token_projmlp, pack_chan_qkv)
 
 T = torch.Tensor
 SD = Dict[str, T]
@@ -64,6 +64,8 @@ _PROJ_MLP = os.environ.get("FF_PROJ_MLP", "1") != "0"
 # DAT SpatialGate: LayerNorm statistics from the fc1 epilogue, normalisation on load in the depth-wise conv: 101 us against
 # 45 + 72 us for the separate LayerNorm pass + plain strip kernel (tools/block_timeline.py).  FF_LN_ON_LOAD=0 restores those.
 _LN_ON_LOAD = os.environ.get("FF_LN_ON_LOAD", "1") != "0"
+# DAT channel attention: LayerNorm + qkv + gram / norms in one launch (csrc/chan_qkv.hip); 0 = token_linear qkv + VALU gram kernel
+_CHAN_FUSED = os.environ.get("FF_CHAN_FUSED", "1") != "0"
 
 
 def _pm(blk: dict) -> dict:
@@ -357,6 +359,12 @@ class DatHIP:
                 ops.win_attn_fused(x, att, pk, blk["relp"][br], gamma=blk["n1"][0], beta=blk["n1"][1], H=H, W=W, Hp=Hp, Wp=Wp,
                                    win=(wh, ww), shift=sh, use_mask=blk["shifted"], head0=hh * br, nheads=hh, zero_pad=True,
                                    v_out=v, v_off=0)
+        elif not blk["spatial"] and _fast() and _CHAN_FUSED:
+            # norm1 + qkv + per-head gram / norms over all tokens in one launch: only v reaches memory (dat_arch.py:617-641)
+            if "cq_pk" not in blk:
+                blk["cq_pk"] = pack_chan_qkv(blk["qkv"][0], blk["qkv"][1], self.heads, C // self.heads)
+            v, wbd = ops.chan_qkv_attn(x, blk["cq_pk"], blk["n1"][0], blk["n1"][1], blk["temp"])
+            qkv = None
         else:
             if _fast():
                 qkv = ops.token_linear(x, _tl(blk, "qkv"), gamma=blk["n1"][0], beta=blk["n1"][1])   # LayerNorm fused
@@ -378,7 +386,8 @@ class DatHIP:
                                     rel_table=blk["rel"][br] if _REL_BIAS else None)
             ch_in, sp_in = conv_x, att
         else:
-            wbd = ops.chan_attn_weights(qkv, 0, C, blk["temp"])
+            if qkv is not None:
+                wbd = ops.chan_attn_weights(qkv, 0, C, blk["temp"])
             att = ops.linear(v, wbd, dynamic_w=True)
             ch_in, sp_in = att, conv_x
         cm = ops.vec_mlp(ops.pool_mean(ch_in), *blk["ci1"], "gelu", *blk["ci4"], "sigmoid")              # [1,C]

@@ -752,6 +752,24 @@ def chan_attn_weights(qkv: T, q_off: int, k_off: int, temperature: T) -> T:
     return wbd
 
 
+def chan_qkv_attn(x: T, pk: dict, gamma: T, beta: T, temperature: T, eps: float = 1e-5):
+    """DAT channel attention front end in two launches (ff_chan_qkv + ff_chan_attn_finish): x [..., 180] ->
+    (v [..., 180], block-diagonal attention matrix [180, 180]); q and k never reach memory."""
+    xp, ldx, rows, K = rows_view(x, "chan_qkv_attn.x")
+    if K != pk["K"]:
+        raise _lib.FFError("chan_qkv_attn: K mismatch")
+    v = empty_like_rows(x)
+    vp, ldv, _, _ = rows_view(v, "chan_qkv_attn.v")
+    nwork = int(_L().ff_chan_qkv_workspace(rows))
+    work = torch.empty(nwork, device=x.device, dtype=torch.float32)
+    wbd = torch.empty((180, 180), device=x.device, dtype=torch.float32)
+    _lib.check(_L().ff_chan_qkv(xp, ldx, rows, K, gamma.data_ptr(), beta.data_ptr(), float(eps), pk["w"].data_ptr(), pk["b"].data_ptr(),
+                                vp, ldv, work.data_ptr(), nwork, _stream()))
+    _lib.check(_L().ff_chan_attn_finish(work.data_ptr(), nwork, (rows + 255) // 256, temperature.data_ptr(), wbd.data_ptr(), _stream()))
+    _note(2.0 * rows * 576 * K + 2.0 * rows * 6 * 32 * 32, 8.0 * rows * K)
+    return v, wbd
+
+
 def band_mha_core(qkv: T, P: int, nbands: int, heads: int) -> T:
     _chk(qkv, "band_mha_core.qkv")
     E = qkv.shape[-1] // 3
@@ -806,6 +824,6 @@ def tile_normalize(acc: T, wsum: T):
 
 
 for _n in ("conv2d", "linear", "win_attn_fused", "token_projmlp", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
-           "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights",
+           "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights", "chan_qkv_attn",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

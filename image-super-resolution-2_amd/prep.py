@@ -192,3 +192,27 @@ def pack_token_projmlp(wp: T, bp: T, w1: T, b1: T, w2: T, b2: T) -> dict:
     mlp = pack_token_mlp(w1perm, b1, w2, b2)
     mlp["K"] = K
     return dict(proj=pack_token_linear(wp, bp), mlp=mlp)
+
+
+def pack_chan_qkv(wqkv: T, bqkv: Optional[T], heads: int = 6, d: int = 30) -> dict:
+    """Weights of ff_chan_qkv from DAT's fused qkv projection [3C, K]: tiles q_0, k_0, ..., q_5, k_5 (each head's 30 rows padded to
+    32), then the v rows in six 32-row tiles; bf16 hi/lo planes, K padded to 192."""
+    C3, K = wqkv.shape
+    C = C3 // 3
+    assert C == heads * d == 180 and K <= 192
+    dev = wqkv.device
+    wt = torch.zeros(18, 32, 192, device=dev)
+    bt = torch.zeros(18, 32, device=dev)
+    for h in range(heads):
+        for j in range(2):
+            rows = slice(j * C + h * d, j * C + (h + 1) * d)
+            wt[2 * h + j, :d, :K] = wqkv[rows]
+            if bqkv is not None:
+                bt[2 * h + j, :d] = bqkv[rows]
+    for t in range(6):
+        n = min(32, C - 32 * t)
+        wt[12 + t, :n, :K] = wqkv[2 * C + 32 * t:2 * C + 32 * t + n]
+        if bqkv is not None:
+            bt[12 + t, :n] = bqkv[2 * C + 32 * t:2 * C + 32 * t + n]
+    hi, lo = split_bf16(wt.reshape(18, 32 * 192))
+    return dict(w=torch.stack([hi, lo], dim=1).contiguous(), b=bt.reshape(-1).contiguous(), K=K)

@@ -262,6 +262,17 @@ int ff_chan_attn_weights(const float* qkv, int ld, int q_off, int k_off, long lo
                          float* wbd, float* work, long long work_floats, void* stream);
 long long ff_chan_attn_workspace(long long N);
 
+/* DAT channel attention, fused front end (csrc/chan_qkv.hip; dat_arch.py:617-641): LayerNorm + qkv projection + per-head gram
+ * q_h^T k_h and squared column norms over all tokens in ONE launch -- q and k never reach memory; v [M][ldv] is written for the
+ * depth-wise branch and the attention product.  w_tiles: bf16 [18][2][32][192] = q_0, k_0, ..., q_5, k_5 (head dim padded to 32
+ * rows) then v rows 0..191 in six tiles (prep.pack_chan_qkv); work: ff_chan_qkv_workspace(M) floats, afterwards holding one
+ * 5760-float partial per 256 tokens.  ff_chan_attn_finish reduces them, L2-normalises, applies the temperature and the softmax and
+ * emits the block-diagonal [180][180] matrix of ff_chan_attn_weights (nblk = ceil(M / 256)). */
+long long ff_chan_qkv_workspace(long long M);
+int ff_chan_qkv(const float* x, int ldx, long long M, int K, const float* gamma, const float* beta, float eps, const void* w_tiles,
+                const float* bias_padded, float* v_out, int ldv, float* work, long long work_floats, void* stream);
+int ff_chan_attn_finish(float* work, long long work_floats, int nblk, const float* temperature, float* wbd, void* stream);
+
 /* Fusion-stack pointwise kernels (see csrc/fusion_ops.hip for the reference lines). */
 int ff_band_mha_core(const float* qkv, float* out, long long P, int nbands, int heads, void* stream);
 int ff_band_weight(const float* x, const float* att, const float* imp, float* out, long long P, int nbands,

@@ -762,3 +762,26 @@ def test_sgfn_layernorm_on_load(dev, H, W):
     assert ((stats[:, 1] - rstd_ref).abs() / rstd_ref).max().item() < 2e-4
     z = ops.dwconv3x3_ln(y[..., Hd // 2:], pack_dw(wd), bd, stats, g2, bb2, mul_in=y[..., :Hd // 2])
     close(z, ref, 1e-4, "SpatialGate with LayerNorm on load")
+
+
+@pytest.mark.parametrize("M", [65536, 3000, 256, 77])
+def test_chan_qkv_attn_fused(dev, M):
+    """DAT channel attention front end (dat_arch.py:617-641): LayerNorm + qkv + per-head L2-normalised gram + temperature + softmax,
+    ff_chan_qkv + ff_chan_attn_finish against the PyTorch fp32 chain; v side output; deterministic."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_chan_qkv
+    C, heads, d = 180, 6, 30
+    x = torch.empty(M, 192, device=dev)[:, :C]
+    x.copy_(rnd(M, C, dev=dev, seed=700, scale=1.4) + 0.2)
+    g, b = rnd(C, dev=dev, seed=701) * 0.1 + 1, rnd(C, dev=dev, seed=702) * 0.1
+    wqkv, bqkv = rnd(3 * C, C, dev=dev, seed=703, scale=1.0 / math.sqrt(C)), rnd(3 * C, dev=dev, seed=704, scale=0.1)
+    temp = (rnd(heads, dev=dev, seed=705) * 0.2 + 1.0).contiguous()
+    v, wbd = ops.chan_qkv_attn(x, pack_chan_qkv(wqkv, bqkv), g, b, temp)
+    qkv = F.linear(F.layer_norm(x, (C,), g, b, 1e-5), wqkv, bqkv).double()
+    q = qkv[:, :C].reshape(M, heads, d).permute(1, 2, 0)
+    k = qkv[:, C:2 * C].reshape(M, heads, d).permute(1, 2, 0)
+    a = torch.softmax((F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)) * temp.double()[:, None, None], dim=-1)
+    close(wbd, torch.block_diag(*[a[h] for h in range(heads)]).float(), 2e-5, "fused channel attention matrix")
+    close(v, qkv[:, 2 * C:].float(), GEMM_TOL["bf16x3"], "v side output")
+    v2, wbd2 = ops.chan_qkv_attn(x, pack_chan_qkv(wqkv, bqkv), g, b, temp)
+    assert torch.equal(wbd, wbd2) and torch.equal(v, v2), "not deterministic"
