@@ -24,6 +24,9 @@ struct TokenLinParams {
   const float* res; const float* res2; const float* rs2;
   float* xn; int ldxn;                     // optional side output: the LayerNorm'ed rows (NULL: not written)
   float* stats; int st_lo, st_hi; float st_eps;   // optional side output: per token (mean, rstd) of OUTPUT channels [st_lo, st_hi)
+  // GATED prologue (DAT adaptive interaction, dat_arch.py:541-556 / :649-664): the GEMM input is  x * cm[channel] + x2 * sm[token],
+  // sm = sigmoid(gw2 . gelu(GW1 x + gb1) + gb2) computed from x itself (GW1: 180 -> 11, BatchNorm folded)
+  const float* x2; int ldx2; const float* cm; const float* gw1t; const float* gb1; const float* gw2; float gb2;
   long long M;
   int ldx, ldo, ldr, ldr2, K, N, NT, act;
   float eps;
@@ -31,7 +34,7 @@ struct TokenLinParams {
 
 #define TL_TR 36   // floats per row of the transpose patch: 144 B keeps rows 16-byte aligned and ds_*_b128 conflict-free
 
-template <int ACT, int TL_KS, bool VEC4>
+template <int ACT, int TL_KS, bool VEC4, bool GATED = false>
 __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
   constexpr int TL_SLOTS = 2 * TL_KS + 1, TL_ROWB = TL_SLOTS * 16, TL_PL = 32 * TL_SLOTS, TL_PIECES = 2 * TL_PL / 64;
   constexpr int TL_TILE_ELEMS = 32 * 16 * TL_KS, KPAD = 16 * TL_KS;
@@ -70,6 +73,91 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
 
   // ---- x rows (+ LayerNorm) -> split bf16 fragments in registers ------------------------------------------------
   bf16x8 xh[TL_KS], xl[TL_KS];
+  if constexpr (GATED) {
+    // DAT's adaptive interaction folded into the projection's prologue: no pixel-gate kernel, no mix kernel, no 47 MB `fused`
+    // tensor.  S = x supplies the per-token gate sm -- its 11-unit first layer is one more 32-row weight tile (index NT of the
+    // image, rows 11..31 zero) against S's own fragments -- and takes the per-channel gate cm; O = x2 takes sm.
+    dma(p.NT, 1);
+    {
+      float v[TL_KS][8];
+      ff_wave_rows_to_frags<TL_KS / 4>(p.x, p.ldx, tok0, p.M, p.K, xs, lane, v);
+#pragma unroll
+      for (int st = 0; st < TL_KS; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const __bf16 h = (__bf16)v[st][j];
+          xh[st][j] = h;
+          xl[st][j] = (__bf16)(v[st][j] - (float)h);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                           // tile 0 (slot 0) and the gate tile (slot 1) landed
+    float sm;
+    {
+      const unsigned char* ap = smem + BUFB + l31 * TL_ROWB + 16 * hh;
+      f32x16 ga;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[r] = p.gb1[(r & 3) + 8 * (r >> 2) + 4 * hh];       // gb1 padded to 32
+      bf16x8 fa[2], fl[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        fa[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u);
+        fl[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u + WB);
+      }
+#pragma unroll
+      for (int st = 0; st < TL_KS; ++st) {
+        const bf16x8 ah = fa[st & 1], al = fl[st & 1];
+        if (st + 2 < TL_KS) {
+          fa[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2));
+          fl[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2) + WB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[st], ga, 0, 0, 0);
+        ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], ga, 0, 0, 0);
+        ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], ga, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float sacc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc += p.gw2[(r & 3) + 8 * (r >> 2) + 4 * hh] * ff_gelu_fast(ga[r]);   // gw2 padded with zeros
+      sacc += __shfl_xor(sacc, 32);
+      sm = 1.0f / (1.0f + expf(-(sacc + p.gb2)));
+    }
+    const int rr = lane >> 4, cq = (lane & 15) * 4;
+#pragma unroll
+    for (int pass = 0; pass < TL_KS / 4; ++pass) {                             // O rows, 64 channels per pass (S occupies the registers)
+      asm volatile("" ::: "memory");                                           // keep the passes apart: hipcc otherwise hoists all 24 row loads (96 VGPRs) above the gate GEMM and spills
+      f32x4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 4 * j + rr, c = 64 * pass + cq;
+        const bool ok = tok0 + r < p.M && c < p.K;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p.x2 + (ok ? (tok0 + r) * p.ldx2 + c : 0));
+        t[j] = ok ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(xs + (4 * j + rr) * FF_XS_ROW + cq) = t[j];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int st = 4 * pass + s4, k0 = 16 * st + 8 * hh;
+        const f32x4 oa = *reinterpret_cast<const f32x4*>(xs + l31 * FF_XS_ROW + 16 * s4 + 8 * hh);
+        const f32x4 ob = *reinterpret_cast<const f32x4*>(xs + l31 * FF_XS_ROW + 16 * s4 + 8 * hh + 4);
+        const int ka = k0 < p.K ? k0 : 0, kb = k0 + 4 < p.K ? k0 + 4 : 0;
+        const f32x4 ca = *reinterpret_cast<const f32x4*>(p.cm + ka), cb = *reinterpret_cast<const f32x4*>(p.cm + kb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float o = j < 4 ? oa[j & 3] : ob[j & 3], cmv = j < 4 ? ca[j & 3] : cb[j & 3];
+          // S is taken back from its own hi + lo split (2^-17 relative: the accuracy the split-bf16 product has anyway), so
+          // the fp32 copy of the rows does not have to stay in registers next to the fragments
+          const float sv = (float)xh[st][j] + (float)xl[st][j];
+          const float f = (k0 + j < p.K) ? sv * cmv + o * sm : 0.f;
+          const __bf16 h = (__bf16)f;
+          xh[st][j] = h;
+          xl[st][j] = (__bf16)(f - (float)h);
+        }
+      }
+    }
+  } else
   {
     float v[TL_KS][8];
     ff_wave_rows_to_frags<TL_KS / 4>(p.x, p.ldx, tok0, p.M, p.K, xs, lane, v);
@@ -278,6 +366,7 @@ extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, lon
   p.K = K; p.N = N; p.NT = n_tiles; p.act = act; p.eps = eps;
   FF_CHECK_ARG(!stats_out || (stat_lo >= 0 && stat_hi > stat_lo && stat_hi <= N && (((uintptr_t)stats_out) & 7) == 0), "ff_token_linear: bad statistics range");
   p.stats = stats_out; p.st_lo = stat_lo; p.st_hi = stat_hi; p.st_eps = stat_eps;
+  p.x2 = nullptr; p.ldx2 = 0; p.cm = nullptr; p.gw1t = nullptr; p.gb1 = nullptr; p.gw2 = nullptr; p.gb2 = 0.f;
   const bool vec4 = (N % 4 == 0) && (ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && (!res || (ldr % 4 == 0 && (((uintptr_t)res) & 15) == 0)) &&
            (!res2 || (ldr2 % 4 == 0 && (((uintptr_t)res2) & 15) == 0 && (((uintptr_t)res2_scale) & 15) == 0));
   const int ks = kpad / 16;
@@ -303,5 +392,38 @@ extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, lon
 #undef TL_LAUNCH_KS
 #undef TL_LAUNCH
   FF_LAUNCH_CHECK("ff_token_linear");
+  return FF_OK;
+}
+
+// out = res + W . ( x * cm[channel] + x2 * sm[token] ) + b,  sm = sigmoid(gw2 . gelu(GW1 x + gb1) + gb2):  DAT's adaptive interaction
+// (channel gate on one branch, spatial gate on the other, dat_arch.py:541-556 spatial blocks / :649-664 channel blocks) + the output
+// projection (:559 / :666) + the block's residual in one launch.  gw1t: [192][12] floats = GW1 transposed and zero padded
+// (11 hidden units, BatchNorm folded), gb1 / gw2: [12].
+extern "C" int ff_token_linear_gated(const float* x, int ldx, const float* x2, int ldx2, const float* cm, const float* gw1t,
+                                     const float* gb1, const float* gw2, float gb2, float* out, int ldo, long long M, int K, int N,
+                                     int n_tiles, const void* w_tiles, const float* bias_padded, const float* res, int ldr, void* stream) {
+  FF_CHECK_ARG(x && x2 && cm && gb1 && gw2 && out && w_tiles, "ff_token_linear_gated: null pointer");   /* gw1t is unused: GW1 travels as tile n_tiles of w_tiles */
+  FF_CHECK_ARG(M > 0 && K > 0 && K <= 192 && K % 4 == 0 && N > 0 && N % 4 == 0 && n_tiles * 32 >= N, "ff_token_linear_gated: needs K <= 192, K and N multiples of 4");
+  FF_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldx2 >= K && ldx2 % 4 == 0 && ldo >= N && ldo % 4 == 0 && (!res || (ldr >= N && ldr % 4 == 0)), "ff_token_linear_gated: rows must be 16-byte aligned");
+  FF_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)x2) | ((uintptr_t)cm) | ((uintptr_t)out) | ((uintptr_t)w_tiles) | ((uintptr_t)res)) & 15) == 0, "ff_token_linear_gated: 16-byte alignment");
+  TokenLinParams p;
+  p.x = x; p.out = out; p.gamma = nullptr; p.beta = nullptr; p.w = (const __bf16*)w_tiles; p.bias = bias_padded;
+  p.res = res; p.res2 = nullptr; p.rs2 = nullptr; p.xn = nullptr; p.ldxn = 0; p.M = M; p.ldx = ldx; p.ldo = ldo; p.ldr = ldr; p.ldr2 = 0;
+  p.K = K; p.N = N; p.NT = n_tiles; p.act = ACT_NONE; p.eps = 0.f;
+  p.stats = nullptr; p.st_lo = 0; p.st_hi = 0; p.st_eps = 0.f;
+  p.x2 = x2; p.ldx2 = ldx2; p.cm = cm; p.gw1t = gw1t; p.gb1 = gb1; p.gw2 = gw2; p.gb2 = gb2;
+  const size_t lds = (size_t)2 * 2 * 32 * 25 * 16 + (size_t)8 * 32 * TL_TR * 4 + (size_t)8 * 32 * FF_XS_ROW * 4 + (size_t)n_tiles * 32 * 4;
+  FF_CHECK_ARG(lds <= 160 * 1024, "ff_token_linear_gated: N too large for the LDS image");
+  const long long nblk = (M + 255) / 256;
+  FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_linear_gated: grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<ACT_NONE, 12, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { ff_set_error("ff_token_linear_gated: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((token_linear_kernel<ACT_NONE, 12, true, true>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  FF_LAUNCH_CHECK("ff_token_linear_gated");
   return FF_OK;
 }

@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from .prep import (pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv, pack_token_mlp, pack_token_linear, pack_naf_ffn,
-                   pack_win_attn, pack_win_rel, pack_token_projmlp, pack_chan_qkv)
+                   pack_win_attn, pack_win_rel, pack_token_projmlp, pack_chan_qkv, pack_token_linear_gated)
 
 T = torch.Tensor
 SD = Dict[str, T]
@@ -66,6 +66,8 @@ _PROJ_MLP = os.environ.get("FF_PROJ_MLP", "1") != "0"
 _LN_ON_LOAD = os.environ.get("FF_LN_ON_LOAD", "1") != "0"
 # DAT channel attention: LayerNorm + qkv + gram / norms in one launch (csrc/chan_qkv.hip); 0 = token_linear qkv + VALU gram kernel
 _CHAN_FUSED = os.environ.get("FF_CHAN_FUSED", "1") != "0"
+# DAT: spatial gate + channel gate + mix + projection + residual in one launch (ff_token_linear_gated); 0 = pixel_mlp, mix2, token_linear
+_GATED_PROJ = os.environ.get("FF_GATED_PROJ", "1") != "0"
 
 
 def _pm(blk: dict) -> dict:
@@ -391,6 +393,12 @@ class DatHIP:
             att = ops.linear(v, wbd, dynamic_w=True)
             ch_in, sp_in = att, conv_x
         cm = ops.vec_mlp(ops.pool_mean(ch_in), *blk["ci1"], "gelu", *blk["ci4"], "sigmoid")              # [1,C]
+        if _fast() and _GATED_PROJ:
+            # spatial gate (from sp_in, applied to ch_in) + channel gate (applied to sp_in) + projection + residual in one launch
+            if "gp_pk" not in blk:
+                blk["gp_pk"] = pack_token_linear_gated(blk["proj"][0], blk["proj"][1], blk["si0"][0], blk["si0"][1], blk["si3"][0])
+            x = ops.token_linear_gated(sp_in, ch_in, blk["gp_pk"], cm.reshape(-1), blk["si3b"], res=x)
+            return self._sgfn(x, blk)
         if _fast():                                                # 180 -> 11 -> 1 per pixel in one pass (fp32)
             sm = ops.pixel_mlp(sp_in, blk["si0"][0], blk["si0"][1], "gelu", blk["si3"][0], blk["si3b"], "sigmoid")
         else:
@@ -400,7 +408,10 @@ class DatHIP:
         else:
             fused = ops.mix2(att, conv_x, pa=sm, cb=cm)
         x = ops.token_linear(fused, _tl(blk, "proj"), res=x) if _fast() else ops.linear(fused, *blk["proj"], res=x)
-        # SGFN
+        return self._sgfn(x, blk)
+
+    def _sgfn(self, x: T, blk: dict) -> T:
+        """x + SGFN(norm2(x)) (dat_arch.py:155-170, :736)."""
         if _fast() and _LN_ON_LOAD:
             # fc1 + GELU also emits the SpatialGate LayerNorm statistics of its upper half; the depth-wise conv normalises on load
             c2 = blk["fc1"][0].shape[0] // 2

@@ -529,6 +529,27 @@ def dwconv2d(x: T, w_tap: T, bias: Optional[T] = None, *, ksize=(3, 3), stride=(
     return out
 
 
+def token_linear_gated(x: T, x2: T, pk: dict, cm: T, gb2: float, *, res: Optional[T] = None) -> T:
+    """res + W (x * cm[channel] + x2 * sm[token]) + b with sm = sigmoid(gw2 . gelu(GW1 x + gb1) + gb2) in one launch (bf16x3);
+    pk from prep.pack_token_linear_gated."""
+    xp, ldx, rows, K = rows_view(x, "token_linear_gated.x")
+    x2p, ldx2, r2, k2 = rows_view(x2, "token_linear_gated.x2")
+    if r2 != rows or k2 != K or K != pk["K"] or cm.numel() != K:
+        raise _lib.FFError("token_linear_gated: shape mismatch")
+    N = pk["N"]
+    out = empty_rows(tuple(x.shape[:-1]) + (N,), x.device)
+    op, ldo, _, _ = rows_view(out, "token_linear_gated.out")
+    rp, ldr = None, 0
+    if res is not None:
+        rp, ldr, rr, rc = rows_view(res, "token_linear_gated.res")
+        if rr != rows or rc != N:
+            raise _lib.FFError("token_linear_gated: res shape mismatch")
+    _lib.check(_L().ff_token_linear_gated(xp, ldx, x2p, ldx2, cm.data_ptr(), None, pk["gb1"].data_ptr(), pk["gw2"].data_ptr(), float(gb2),
+                                          op, ldo, rows, K, N, pk["nt"], pk["w"].data_ptr(), pk["b"].data_ptr(), rp, ldr, _stream()))
+    _note(2.0 * rows * N * K + 2.0 * rows * 32 * K, 4.0 * rows * (2 * K + N * (2 if res is not None else 1)))
+    return out
+
+
 def dwconv3x3_ln(x: T, w_tap: T, bias: Optional[T], stats: T, gamma: T, beta: T, mul_in: Optional[T] = None) -> T:
     """(dw3x3(LayerNorm(x)) + bias) * mul_in with the LayerNorm applied on load from per-token (mean, rstd) `stats`."""
     xp, ldi, B, H, W, C = _nhwc(x, "dwconv3x3_ln.x")
@@ -823,7 +844,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "linear", "win_attn_fused", "token_projmlp", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
+for _n in ("conv2d", "linear", "win_attn_fused", "token_projmlp", "token_linear_gated", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights", "chan_qkv_attn",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

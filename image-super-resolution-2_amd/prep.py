@@ -216,3 +216,25 @@ def pack_chan_qkv(wqkv: T, bqkv: Optional[T], heads: int = 6, d: int = 30) -> di
             bt[12 + t, :n] = bqkv[2 * C + 32 * t:2 * C + 32 * t + n]
     hi, lo = split_bf16(wt.reshape(18, 32 * 192))
     return dict(w=torch.stack([hi, lo], dim=1).contiguous(), b=bt.reshape(-1).contiguous(), K=K)
+
+
+def pack_token_linear_gated(w: T, b: Optional[T], gw1: T, gb1: Optional[T], gw2: T) -> dict:
+    """Weights of ff_token_linear_gated: the projection [N, K] as in pack_token_linear plus one more tile with the spatial gate's
+    first layer GW1 [hidden <= 32, K]; its bias and the second layer's weights zero padded to 32."""
+    N, K = w.shape
+    hd = gw1.shape[0]
+    assert K <= 192 and hd <= 32 and gw1.shape[1] == K
+    nt = (N + 31) // 32
+    wp = torch.zeros((nt + 1) * 32, 192, device=w.device)
+    wp[:N, :K] = w
+    wp[nt * 32:nt * 32 + hd, :K] = gw1
+    hi, lo = split_bf16(wp.reshape(nt + 1, 32 * 192))
+    bp = torch.zeros(nt * 32, device=w.device)
+    if b is not None:
+        bp[:N] = b
+    g1 = torch.zeros(32, device=w.device)
+    if gb1 is not None:
+        g1[:hd] = gb1
+    g2 = torch.zeros(32, device=w.device)
+    g2[:hd] = gw2.reshape(-1)
+    return dict(nt=nt, K=K, N=N, w=torch.stack([hi, lo], dim=1).contiguous(), b=bp, gb1=g1, gw2=g2)

@@ -158,6 +158,17 @@ int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, i
                     float* xn_out, int ldxn, float* stats_out, int stat_lo,
                     int stat_hi, float stat_eps, void* stream);
 
+/* ff_token_linear with DAT's adaptive-interaction prologue (csrc/token_linear.hip, GATED): the GEMM input is
+ *   x * cm[channel] + x2 * sm[token],   sm = sigmoid(gw2 . gelu(GW1 x + gb1) + gb2)
+ * i.e. the channel gate on one branch, the spatial gate (conv1x1 180->11 (+BN folded) -> GELU -> conv1x1 11->1 -> sigmoid,
+ * dat_arch.py:585-590) computed from that same branch and applied to the other, then the output projection + bias + residual
+ * (dat_arch.py:541-559 spatial blocks with x = attention, x2 = conv; :649-666 channel blocks with x = conv, x2 = attention).
+ * w_tiles: prep.pack_token_linear_gated = the projection's tiles followed by ONE more 32-row tile holding GW1 (rows 11..31 zero);
+ * gb1 / gw2: [32] zero padded.  Replaces ff_pixel_mlp + ff_mix2 + ff_token_linear and the 47 MB tensor between them. */
+int ff_token_linear_gated(const float* x, int ldx, const float* x2, int ldx2, const float* cm, const float* gw1t, const float* gb1,
+                          const float* gw2, float gb2, float* out, int ldo, long long M, int K, int N, int n_tiles,
+                          const void* w_tiles, const float* bias_padded, const float* res, int ldr, void* stream);
+
 /* NAFNet block fusions (csrc/naf_fused.hip).
  * ff_dwconv3_gate_pool: out[p][c] = dw3x3(in)[p][c] * dw3x3(in)[p][C + c] (conv2 + SimpleGate, nafnet_arch.py:78-81,51-52)
  *   and pooled[c] = mean_p out[p][c] (the SCA pool, :86) in one pass.  in [H][W][ldi] with 2C channels, weights tap-major

@@ -785,3 +785,26 @@ def test_chan_qkv_attn_fused(dev, M):
     close(v, qkv[:, 2 * C:].float(), GEMM_TOL["bf16x3"], "v side output")
     v2, wbd2 = ops.chan_qkv_attn(x, pack_chan_qkv(wqkv, bqkv), g, b, temp)
     assert torch.equal(wbd, wbd2) and torch.equal(v, v2), "not deterministic"
+
+
+@pytest.mark.parametrize("M", [65536, 1000, 77])
+def test_token_linear_gated(dev, M):
+    """DAT adaptive interaction + projection + residual in one launch (dat_arch.py:541-559 / :649-666) against the PyTorch chain:
+    sm = sigmoid(w2 . gelu(W1 s + b1) + b2), out = res + proj(s * cm + o * sm)."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_token_linear_gated
+    C, Hd = 180, 11
+    sp = torch.empty(M, 192, device=dev)[:, :C]
+    sp.copy_(rnd(M, C, dev=dev, seed=800))
+    ch = torch.empty(M, 192, device=dev)[:, :C]
+    ch.copy_(rnd(M, C, dev=dev, seed=801))
+    res = torch.empty(M, 192, device=dev)[:, :C]
+    res.copy_(rnd(M, C, dev=dev, seed=802))
+    cm = torch.sigmoid(rnd(C, dev=dev, seed=803)).contiguous()
+    w1, b1 = rnd(Hd, C, dev=dev, seed=804, scale=1.0 / math.sqrt(C)), rnd(Hd, dev=dev, seed=805, scale=0.1)
+    w2, b2 = rnd(1, Hd, dev=dev, seed=806, scale=0.5), 0.13
+    wp, bp = rnd(C, C, dev=dev, seed=807, scale=1.0 / math.sqrt(C)), rnd(C, dev=dev, seed=808, scale=0.1)
+    sm = torch.sigmoid(F.linear(F.gelu(F.linear(sp, w1, b1)), w2) + b2)
+    ref = res + F.linear(sp * cm + ch * sm, wp, bp)
+    out = ops.token_linear_gated(sp, ch, pack_token_linear_gated(wp, bp, w1, b1, w2), cm, b2, res=res)
+    close(out, ref, GEMM_TOL["bf16x3"], "token_linear_gated")
