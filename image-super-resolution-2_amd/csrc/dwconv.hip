@@ -105,6 +105,69 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(DwParams p) {
   }
 }
 
+// Register-tiled depth-wise convolution, stride 1, "same" padding, for the large kernels of the LKA chain
+// (large_kernel_attention.py:59-78: 5x5, 1x21, 21x1 on 9 x 64 channels) and the 5x5 Gaussian (edge_enhancement.py:62):
+// a thread owns 4 channels of an RY x RX output patch and loads its (RY+KH-1) x (RX+KW-1) input window ONCE -- 3.5 (1x21), 3.5 (21x1)
+// and 9 (5x5) float4 loads per output instead of one per tap (the generic kernel ran the chain at 1 TB/s).
+template <int KH, int KW, int RY, int RX>
+__global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
+  constexpr int IY = RY + KH - 1, IX = RX + KW - 1;
+  const int c4n = p.C >> 2;
+  const int ny = (p.H + RY - 1) / RY, nx = (p.W + RX - 1) / RX;
+  const long long total = (long long)p.B * ny * nx * c4n;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % c4n) * 4;
+    long long t = idx / c4n;
+    const int x0 = (int)(t % nx) * RX; t /= nx;
+    const int y0 = (int)(t % ny) * RY;
+    const int b = (int)(t / ny);
+    f32x4 in[IY][IX];
+#pragma unroll
+    for (int r = 0; r < IY; ++r) {
+      const int iy = y0 - p.py + r;
+      const bool oky = (unsigned)iy < (unsigned)p.H;
+#pragma unroll
+      for (int k = 0; k < IX; ++k) {
+        const int ix = x0 - p.px + k;
+        const bool ok = oky && (unsigned)ix < (unsigned)p.W;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p.in + (ok ? ((long long)(b * p.H + iy) * p.W + ix) * p.ldi + c : 0));
+        in[r][k] = ok ? u : z4;
+      }
+    }
+    f32x4 acc[RY][RX];
+#pragma unroll
+    for (int r = 0; r < RY; ++r)
+#pragma unroll
+      for (int k = 0; k < RX; ++k) acc[r][k] = z4;
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + (long long)(ky * KW + kx) * p.C + c);
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+#pragma unroll
+          for (int k = 0; k < RX; ++k) acc[r][k] += in[r + ky][k + kx] * w;
+      }
+    const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : z4;
+    f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pt = z4;
+    if (p.ps) { ps = *reinterpret_cast<const f32x4*>(p.ps + c); pt = *reinterpret_cast<const f32x4*>(p.pt + c); }
+#pragma unroll
+    for (int r = 0; r < RY; ++r)
+#pragma unroll
+      for (int k = 0; k < RX; ++k) {
+        if (y0 + r >= p.H || x0 + k >= p.W) continue;
+        const long long pix = (long long)(b * p.H + y0 + r) * p.W + x0 + k;
+        f32x4 v = (acc[r][k] + bias) * ps + pt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ff_act(v[e], p.act);
+        if (p.mulin) v *= *reinterpret_cast<const f32x4*>(p.mulin + pix * p.ldm + c);
+        *reinterpret_cast<f32x4*>(p.out + pix * p.ldo + c) = v;
+      }
+  }
+}
+
 // The same strip kernel with LayerNorm applied ON LOAD (DAT SpatialGate, dat_arch.py:117-122: x2 -> LayerNorm -> dw3x3, times x1):
 // the per-token (mean, rstd) come from the producer's epilogue (ff_token_linear stats_out), gamma / beta per channel; the
 // convolution's zero padding applies to the NORMALISED tensor, so out-of-image taps contribute exactly zero.
@@ -230,6 +293,18 @@ extern "C" int ff_dwconv2d(const float* in, int ldi, float* out, int ldo, int B,
       hipLaunchKernelGGL((dwconv3x3_strip_kernel<decltype(A)::value>), dim3((unsigned)nbs), dim3(256), 0, (hipStream_t)stream, p);
     };
     FF_DISPATCH_ACT(act, go);
+    FF_LAUNCH_CHECK("ff_dwconv2d");
+    return FF_OK;
+  }
+  if (v4 && sy == 1 && sx == 1 && Ho == H && Wo == W && out != in && py == KH / 2 && px == KW / 2 &&
+      ((KH == 1 && KW == 21) || (KH == 21 && KW == 1) || (KH == 5 && KW == 5))) {
+    const int ry = KH == 21 ? 8 : (KH == 5 ? 2 : 1), rx = KW == 21 ? 8 : (KW == 5 ? 2 : 1);
+    const long long tot = (long long)B * ((H + ry - 1) / ry) * ((W + rx - 1) / rx) * (C / 4);
+    long long nbt = (tot + 255) / 256;
+    if (nbt > 256 * 32) nbt = 256 * 32;
+    if (KW == 21) hipLaunchKernelGGL((dwconv_tile_kernel<1, 21, 1, 8>), dim3((unsigned)nbt), dim3(256), 0, (hipStream_t)stream, p);
+    else if (KH == 21) hipLaunchKernelGGL((dwconv_tile_kernel<21, 1, 8, 1>), dim3((unsigned)nbt), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((dwconv_tile_kernel<5, 5, 2, 2>), dim3((unsigned)nbt), dim3(256), 0, (hipStream_t)stream, p);
     FF_LAUNCH_CHECK("ff_dwconv2d");
     return FF_OK;
   }

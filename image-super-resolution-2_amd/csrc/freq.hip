@@ -103,34 +103,47 @@ extern "C" int ff_dwt_pass(const float* in, int C, int H, int W, int axis, const
 // ------------------------------------------------------------------------------------------ FFT bands
 // rfft2/irfft2 ('ortho') as direct DFTs with host-built twiddle tables tw[n] = (cos, sin)(2 pi n / N):
 // 256x256x3 needs ~0.6 GFLOP -- cheaper than any launch-heavy radix pipeline at this size.
+// Round 2: the twiddle tables live in LDS (the global-memory version spent its time in 256 dependent L1 round trips per output:
+// 505 us for 3 x 256 x 256), the inner loops run four independent partial sums, and the column passes are split over key ranges
+// so that a 256 x 129 spectrum gives 200+ workgroups instead of 27.
 __global__ __launch_bounds__(256) void rdft_rows_kernel(const float* __restrict__ x, int R, int W, const float* __restrict__ tc,
                                                         const float* __restrict__ ts, float* __restrict__ Y) {
-  extern __shared__ float row[];
+  extern __shared__ float sm[];                            // row[W] | cos[W] | sin[W]
+  float* row = sm; float* cs = sm + W; float* sn = sm + 2 * W;
   const int r = blockIdx.x, Wf = W / 2 + 1;
-  for (int i = threadIdx.x; i < W; i += 256) row[i] = x[(long long)r * W + i];
+  for (int i = threadIdx.x; i < W; i += 256) { row[i] = x[(long long)r * W + i]; cs[i] = tc[i]; sn[i] = ts[i]; }
   __syncthreads();
   const float nrm = 1.0f / sqrtf((float)W);
   for (int k = threadIdx.x; k < Wf; k += 256) {
-    float re = 0.f, im = 0.f;
-    int idx = 0;
-    for (int n = 0; n < W; ++n) {
-      re += row[n] * tc[idx];
-      im -= row[n] * ts[idx];
+    float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f};
+    int idx = 0, n = 0;
+    for (; n + 3 < W; n += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        re[u] += row[n + u] * cs[idx];
+        im[u] -= row[n + u] * sn[idx];
+        idx += k;
+        if (idx >= W) idx -= W;
+      }
+    }
+    for (; n < W; ++n) {
+      re[0] += row[n] * cs[idx]; im[0] -= row[n] * sn[idx];
       idx += k;
       if (idx >= W) idx -= W;
     }
-    Y[((long long)r * Wf + k) * 2] = re * nrm;
-    Y[((long long)r * Wf + k) * 2 + 1] = im * nrm;
+    Y[((long long)r * Wf + k) * 2] = ((re[0] + re[1]) + (re[2] + re[3])) * nrm;
+    Y[((long long)r * Wf + k) * 2 + 1] = ((im[0] + im[1]) + (im[2] + im[3])) * nrm;
   }
 }
 
-// column DFT over H for CB columns per workgroup; sign = -1 forward, +1 inverse.  With mask_logits the
-// output is multiplied by sigmoid(bilinear(logits)[kh][kw] * temp) (multi_domain_frequency.py:366-374).
-__global__ __launch_bounds__(256) void cdft_cols_kernel(const float* __restrict__ Yin, int H, int Wf, int CB, float sign,
+// column DFT over H for CB columns per workgroup and the output rows [blockIdx.z * KH, +KH); sign = -1 forward, +1 inverse.
+// With mask_logits the output is multiplied by sigmoid(bilinear(logits)[kh][kw] * temp) (multi_domain_frequency.py:366-374).
+__global__ __launch_bounds__(256) void cdft_cols_kernel(const float* __restrict__ Yin, int H, int Wf, int CB, int KH, float sign,
                                                         const float* __restrict__ tc, const float* __restrict__ ts,
                                                         const float* __restrict__ mask_logits, int msz, float temp,
                                                         float* __restrict__ Z) {
-  extern __shared__ float tile[];                         // [H][CB][2]
+  extern __shared__ float sm[];                           // tile [H][CB][2] | cos[H] | sin[H]
+  float* tile = sm; float* cs = sm + 2 * H * CB; float* sn = cs + H;
   const int c = blockIdx.y, col0 = blockIdx.x * CB;
   for (int i = threadIdx.x; i < H * CB; i += 256) {
     const int h = i / CB, cc = i % CB;
@@ -142,21 +155,33 @@ __global__ __launch_bounds__(256) void cdft_cols_kernel(const float* __restrict_
     }
     tile[2 * i] = re; tile[2 * i + 1] = im;
   }
+  for (int i = threadIdx.x; i < H; i += 256) { cs[i] = tc[i]; sn[i] = sign * ts[i]; }      // e^{sign * i theta}
   __syncthreads();
   const float nrm = 1.0f / sqrtf((float)H);
   const int cc = threadIdx.x % CB, col = col0 + cc;
-  for (int kh = threadIdx.x / CB; kh < H; kh += 256 / CB) {
-    float re = 0.f, im = 0.f;
-    int idx = 0;
-    for (int h = 0; h < H; ++h) {
+  const int kh_end = min(H, (int)(blockIdx.z + 1) * KH);
+  for (int kh = blockIdx.z * KH + threadIdx.x / CB; kh < kh_end; kh += 256 / CB) {
+    float re[2] = {0.f, 0.f}, im[2] = {0.f, 0.f};
+    int idx = 0, h = 0;
+    for (; h + 1 < H; h += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float a = tile[2 * ((h + u) * CB + cc)], b = tile[2 * ((h + u) * CB + cc) + 1];
+        const float cw = cs[idx], sw = sn[idx];
+        re[u] += a * cw - b * sw;
+        im[u] += a * sw + b * cw;
+        idx += kh;
+        if (idx >= H) idx -= H;
+      }
+    }
+    for (; h < H; ++h) {
       const float a = tile[2 * (h * CB + cc)], b = tile[2 * (h * CB + cc) + 1];
-      const float cs = tc[idx], sn = sign * ts[idx];      // e^{sign * i theta}
-      re += a * cs - b * sn;
-      im += a * sn + b * cs;
+      re[0] += a * cs[idx] - b * sn[idx];
+      im[0] += a * sn[idx] + b * cs[idx];
       idx += kh;
       if (idx >= H) idx -= H;
     }
-    re *= nrm; im *= nrm;
+    float rr = (re[0] + re[1]) * nrm, ii = (im[0] + im[1]) * nrm;
     if (col < Wf) {
       if (mask_logits) {
         const float sh = (float)msz / (float)H, sw = (float)msz / (float)Wf;
@@ -169,10 +194,10 @@ __global__ __launch_bounds__(256) void cdft_cols_kernel(const float* __restrict_
         const float lg = (1.f - ly) * ((1.f - lx) * mask_logits[y0 * msz + x0] + lx * mask_logits[y0 * msz + x1]) +
                          ly * ((1.f - lx) * mask_logits[y1 * msz + x0] + lx * mask_logits[y1 * msz + x1]);
         const float m = 1.0f / (1.0f + expf(-lg * temp));
-        re *= m; im *= m;
+        rr *= m; ii *= m;
       }
       const long long o = (((long long)c * H + kh) * Wf + col) * 2;
-      Z[o] = re; Z[o + 1] = im;
+      Z[o] = rr; Z[o + 1] = ii;
     }
   }
 }
@@ -182,22 +207,32 @@ __global__ __launch_bounds__(256) void irdft_rows_bands_kernel(const float* __re
                                                                int H, int W, const float* __restrict__ tc,
                                                                const float* __restrict__ ts, const float* __restrict__ bscale,
                                                                float* __restrict__ out, int ldo, int ch_lo, int ch_hi) {
-  extern __shared__ float urow[];                         // [Wf][2]
+  extern __shared__ float sm[];                           // urow[Wf][2] | cos[W] | sin[W]
   const int r = blockIdx.x, Wf = W / 2 + 1, c = r / H, y = r % H;
+  float* urow = sm; float* cs = sm + 2 * Wf; float* sn = cs + W;
   for (int i = threadIdx.x; i < 2 * Wf; i += 256) urow[i] = U[(long long)r * Wf * 2 + i];
+  for (int i = threadIdx.x; i < W; i += 256) { cs[i] = tc[i]; sn[i] = ts[i]; }
   __syncthreads();
   const float nrm = 1.0f / sqrtf((float)W);
   const int kmax = (W - 1) / 2;                           // bins with a conjugate partner
   for (int w = threadIdx.x; w < W; w += 256) {
-    float s = urow[0];
-    if ((W & 1) == 0) s += ((w & 1) ? -1.f : 1.f) * urow[2 * (W / 2)];
-    int idx = 0;
-    for (int k = 1; k <= kmax; ++k) {
+    float s0 = urow[0], s1 = 0.f;
+    if ((W & 1) == 0) s0 += ((w & 1) ? -1.f : 1.f) * urow[2 * (W / 2)];
+    int idx = 0, k = 1;
+    for (; k + 1 <= kmax; k += 2) {
       idx += w;
       if (idx >= W) idx -= W;
-      s += 2.f * (urow[2 * k] * tc[idx] - urow[2 * k + 1] * ts[idx]);
+      s0 += 2.f * (urow[2 * k] * cs[idx] - urow[2 * k + 1] * sn[idx]);
+      idx += w;
+      if (idx >= W) idx -= W;
+      s1 += 2.f * (urow[2 * k + 2] * cs[idx] - urow[2 * k + 3] * sn[idx]);
     }
-    s *= nrm;
+    for (; k <= kmax; ++k) {
+      idx += w;
+      if (idx >= W) idx -= W;
+      s0 += 2.f * (urow[2 * k] * cs[idx] - urow[2 * k + 1] * sn[idx]);
+    }
+    const float s = (s0 + s1) * nrm;
     const float xv = x[(long long)r * W + w];
     float* o = out + ((long long)y * W + w) * ldo;
     o[ch_lo + c] = s * bscale[0];
@@ -217,15 +252,21 @@ extern "C" int ff_fft_bands(const float* x, int C, int H, int W, const float* tw
   float* Y = work;
   float* Z = work + spec;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(rdft_rows_kernel, dim3(C * H), dim3(256), (size_t)W * 4, st, x, C * H, W, twW_cos, twW_sin, Y);
+  hipLaunchKernelGGL(rdft_rows_kernel, dim3(C * H), dim3(256), (size_t)W * 12, st, x, C * H, W, twW_cos, twW_sin, Y);
   const int CB = H <= 512 ? 16 : 4;
-  FF_CHECK_ARG((size_t)H * CB * 8 <= 64 * 1024, "ff_fft_bands: H too large for the column tile");
-  dim3 gc((Wf + CB - 1) / CB, C);
-  hipLaunchKernelGGL(cdft_cols_kernel, gc, dim3(256), (size_t)H * CB * 8, st, Y, H, Wf, CB, -1.f, twH_cos, twH_sin, mask_logits,
+  const size_t clds = (size_t)H * CB * 8 + (size_t)H * 8;
+  FF_CHECK_ARG(clds <= 64 * 1024, "ff_fft_bands: H too large for the column tile");
+  // split the output rows of a column block over workgroups until the grid has a few per CU
+  const int ncb = (Wf + CB - 1) / CB;
+  int ksplit = 1;
+  while (ncb * C * ksplit < 512 && (H + ksplit - 1) / ksplit > 256 / CB) ksplit *= 2;
+  const int KH = (H + ksplit - 1) / ksplit;
+  dim3 gc(ncb, C, (H + KH - 1) / KH);
+  hipLaunchKernelGGL(cdft_cols_kernel, gc, dim3(256), clds, st, Y, H, Wf, CB, KH, -1.f, twH_cos, twH_sin, mask_logits,
                      msz, temp, Z);
-  hipLaunchKernelGGL(cdft_cols_kernel, gc, dim3(256), (size_t)H * CB * 8, st, Z, H, Wf, CB, 1.f, twH_cos, twH_sin,
+  hipLaunchKernelGGL(cdft_cols_kernel, gc, dim3(256), clds, st, Z, H, Wf, CB, KH, 1.f, twH_cos, twH_sin,
                      (const float*)nullptr, 0, 0.f, Y);
-  hipLaunchKernelGGL(irdft_rows_bands_kernel, dim3(C * H), dim3(256), (size_t)Wf * 8, st, Y, x, C, H, W, twW_cos, twW_sin,
+  hipLaunchKernelGGL(irdft_rows_bands_kernel, dim3(C * H), dim3(256), (size_t)Wf * 8 + (size_t)W * 8, st, Y, x, C, H, W, twW_cos, twW_sin,
                      band_scale2, out, ldo, ch_lo, ch_hi);
   FF_LAUNCH_CHECK("ff_fft_bands");
   return FF_OK;

@@ -17,6 +17,7 @@
 //              O^T is transposed through the wave's own (now idle) K rows and stored as 120-byte row segments.
 // HBM traffic per launch: x in, attention out (+ the optional side output): 2-3 x 47 MB instead of 47+141+47 | 141+180+47.
 #include "ff_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -29,7 +30,7 @@ struct WinFusedParams {
   float* xn; float* vout;
   int ldx, ldo, ldxn, ldv, o_off, v_off;
   int B, H, W, Hp, Wp, sh, sw, use_mask, nwx, nwy;
-  int head0, nheads, d, K, zero_pad, rel_rows, rel_stride;
+  int head0, nheads, d, K, zero_pad, rel_rows, rel_stride, prio;
   float eps;
 };
 
@@ -57,7 +58,7 @@ struct WinFusedParams {
 #define WF_LDS (WF_OFF_SAME + 9 * 8 * 4)
 #define WF_XS_ROW 68
 
-template <int WW, int NTERMS>
+template <int WW, int NTERMS, int UNR>
 __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
   constexpr int WH = 256 / WW;
   // row stride of the compact bias table: >= 2 WW - 1 and == WW (mod 32), so the WH' rows of queries a 32-lane group spans
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
     if (it + 1 < ntiles) dma(tile0 + it + 1, (it + 1) & 1);
   };
 
+  if (p.prio && wid >= 4) __builtin_amdgcn_s_setprio(1);       // static priority for the younger half (guide: two waves per SIMD, item 4)
   for (int hi = 0; hi < p.nheads; ++hi) {
     const int g = p.head0 + hi;
     // this head's compact bias table -> LDS (every wave is past the previous head's attention: barrier at the loop end)
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
     const unsigned char* kp = KB + l31 * WF_KROWB + 16 * hh;
     const unsigned char* vq = VB + l31 * WF_VROWB + 16 * hh;
     const unsigned* samep = same + 8 * qreg_id;
-#pragma unroll 1
+#pragma unroll UNR
     for (int t = 0; t < 8; ++t, relp -= (32 / WW) * RS, kp += WF_KWAVE, vq += 64) {
       f32x16 st;
 #pragma unroll
@@ -477,19 +479,24 @@ extern "C" int ff_win_attn_fused(const float* x, int ldx, float* out, int ldo, i
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_win_attn_fused: grid too large");
   static_assert(WF_LDS <= 160 * 1024, "LDS image too large");
   static_assert(8 * 32 * WF_XS_ROW * 4 <= 8 * WF_KWAVE + 2 * WF_VPLB, "gather patch must fit in the K / V area");
-#define WF_LAUNCH(WWV, NT)                                                                                                    \
+  static int unr = -1, prio = -1;
+  if (unr < 0) { const char* e = getenv("FF_WF_UNROLL"); unr = (e && e[0] == '1') ? 1 : 2; const char* q = getenv("FF_WF_PRIO"); prio = (q && q[0] == '1') ? 1 : 0; }
+  p.prio = prio;
+#define WF_LAUNCH1(WWV, NT, U)                                                                                                \
   do {                                                                                                                        \
     static bool attr_set = false;                                                                                             \
     if (!attr_set) {                                                                                                          \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_attn_fused_kernel<WWV, NT>),                      \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_attn_fused_kernel<WWV, NT, U>),                   \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);                                 \
       if (e != hipSuccess) { ff_set_error("ff_win_attn_fused: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; } \
       attr_set = true;                                                                                                        \
     }                                                                                                                         \
-    hipLaunchKernelGGL((win_attn_fused_kernel<WWV, NT>), dim3((unsigned)nblk), dim3(512), WF_LDS, (hipStream_t)stream, p);    \
+    hipLaunchKernelGGL((win_attn_fused_kernel<WWV, NT, U>), dim3((unsigned)nblk), dim3(512), WF_LDS, (hipStream_t)stream, p); \
   } while (0)
+#define WF_LAUNCH(WWV, NT) do { if (unr == 1) WF_LAUNCH1(WWV, NT, 1); else WF_LAUNCH1(WWV, NT, 2); } while (0)
   if (nterms == 3) { if (ww == 8) WF_LAUNCH(8, 3); else if (ww == 16) WF_LAUNCH(16, 3); else WF_LAUNCH(32, 3); }
   else { if (ww == 8) WF_LAUNCH(8, 1); else if (ww == 16) WF_LAUNCH(16, 1); else WF_LAUNCH(32, 1); }
+#undef WF_LAUNCH1
 #undef WF_LAUNCH
   FF_LAUNCH_CHECK("ff_win_attn_fused");
   return FF_OK;

@@ -217,7 +217,14 @@ class HierFusion:
         k = self.st[name]
         x = ops.conv2d(x, *k["c0"], ksize=(3, 3), pad=(1, 1), act="gelu")
         x = ops.conv2d(x, *k["c2"], ksize=(3, 3), pad=(1, 1), act="gelu")
-        gate = ops.linear(ops.linear(x, *k["g0"], act="gelu"), *k["g2"], act="sigmoid")    # [.,1]
+        if ops.gemm_mode() != "f32" and k["g0"][0].shape[0] <= 16:
+            # SpatialGate (hierarchical_fusion.py:25-43): conv1x1 C -> C/4 -> GELU -> conv1x1 -> 1 -> sigmoid per pixel in ONE pass over x
+            # (fp32 VALU, ff_pixel_mlp) instead of two N <= 16 GEMM launches that re-read the 64-channel tensor
+            if "g2b" not in k:
+                k["g2b"] = float(k["g2"][1].reshape(-1)[0].cpu())
+            gate = ops.pixel_mlp(x, k["g0"][0], k["g0"][1], "gelu", k["g2"][0], k["g2b"], "sigmoid")
+        else:
+            gate = ops.linear(ops.linear(x, *k["g0"], act="gelu"), *k["g2"], act="sigmoid")    # [.,1]
         x = ops.mix2(x, pa=gate)
         r = ops.conv2d(x, *k["r0"], ksize=(3, 3), pad=(1, 1), act="gelu")
         return ops.conv2d(r, *k["r2"], ksize=(3, 3), pad=(1, 1), res=x, alpha=k["rs"])

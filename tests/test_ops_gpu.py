@@ -808,3 +808,29 @@ def test_token_linear_gated(dev, M):
     ref = res + F.linear(sp * cm + ch * sm, wp, bp)
     out = ops.token_linear_gated(sp, ch, pack_token_linear_gated(wp, bp, w1, b1, w2), cm, b2, res=res)
     close(out, ref, GEMM_TOL["bf16x3"], "token_linear_gated")
+
+
+def test_bilinear_vec4_nhwc(dev):
+    """float4 channel-last bilinear path (C % 4 == 0, 16-byte aligned rows) incl. writing into a channel slice of a wider buffer."""
+    from isr2_amd import ops
+    x = rnd(1, 64, 37, 45, dev=dev, seed=900)
+    ref = F.interpolate(x, size=(74, 90), mode="bilinear", align_corners=False)
+    buf = torch.zeros(1, 74, 90, 76, device=dev)
+    ops.resize(x.permute(0, 2, 3, 1).contiguous(), (74, 90), out=buf[..., :64], mul=0.5)
+    close(buf[..., :64].permute(0, 3, 1, 2), 0.5 * ref, 2e-6, "bilinear vec4")
+    assert buf[..., 64:].abs().max() == 0
+    down = ops.resize(x.permute(0, 2, 3, 1).contiguous(), (18, 22), scale_factor=0.5)
+    close(down.permute(0, 3, 1, 2), F.interpolate(x, scale_factor=0.5, mode="bilinear", align_corners=False), 2e-6, "bilinear vec4 down")
+
+
+@pytest.mark.parametrize("kh,kw", [(5, 5), (1, 21), (21, 1)])
+def test_dwconv_large_kernels_at_bench_size(dev, kh, kw):
+    """The register-tiled depth-wise kernels of the LKA chain on its real geometry (9 x 64 channels at 256 x 256)."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_dw
+    C = 576
+    x = rnd(1, C, 256, 256, dev=dev, seed=910)
+    w = rnd(C, 1, kh, kw, dev=dev, seed=911, scale=0.2)
+    ref = F.conv2d(x, w, None, padding=(kh // 2, kw // 2), groups=C)
+    out = ops.dwconv2d(x.permute(0, 2, 3, 1).contiguous(), pack_dw(w), None, ksize=(kh, kw), pad=(kh // 2, kw // 2))
+    close(out.permute(0, 3, 1, 2), ref, 1e-5, "dwconv large kernel")
