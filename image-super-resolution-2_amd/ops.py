@@ -91,6 +91,7 @@ def gemm_mode() -> str:
     return _GEMM_MODE
 
 
+_SMALL = _os.environ.get("FF_SMALL_CONV", "1") != "0"     # fp32 VALU kernel for 3x3 convolutions with Cout <= 16, Cin <= 64
 _HALO_ALL = _os.environ.get("FF_HALO", "1") == "2"          # tuning aid: every eligible 3x3 through the halo kernel
 _HALO = _os.environ.get("FF_HALO", "1") != "0"     # LDS-resident 3x3 convolution (csrc/conv3x3_halo.hip); 0 = generic implicit GEMM
 
@@ -209,7 +210,16 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
         if tuple(res.shape) != oshape:
             raise _lib.FFError(f"conv2d: res shape {tuple(res.shape)} != {oshape}")
         rp, ldr, *_ = _nhwc(res, "conv2d.res")
-    if _GEMM_MODE == "f32":
+    if (_SMALL and _GEMM_MODE != "f32" and (KH, KW) == (3, 3) and tuple(stride) == (1, 1) and tuple(pad) == (1, 1) and Cout <= 16
+            and Cin <= 64 and shuffle == 0 and mul is None and not dynamic_w and H * W >= 4096 and xp != op):
+        # small-channel tail convolutions: exact fp32 on the VALU from an LDS halo tile (csrc/conv3x3_small.hip)
+        ws = getattr(w, "_ff_small", None)
+        if ws is None:
+            from . import prep as _prep
+            ws = w._ff_small = _prep.pack_conv3x3_small(w, Cin)
+        _lib.check(_L().ff_conv3x3_small(xp, ldi, ws.data_ptr(), ws.shape[2], _ptr(bias), rp, ldr, op, ldo, B, H, W, Cin, Cout, ACT[act],
+                                         float(alpha), _stream()))
+    elif _GEMM_MODE == "f32":
         _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, B, H, W, Cin, ldi, Ho, Wo, Cout, ldo, ldr,
                                   KH, KW, stride[0], stride[1], pad[0], pad[1], ACT[act], float(alpha), shuffle, tile_hint,
                                   _stream()))

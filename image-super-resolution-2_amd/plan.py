@@ -44,7 +44,7 @@ def _walk_tensors(obj, path: str, out: Dict[int, Tuple[str, torch.Tensor]], seen
         if obj.is_cuda:
             st = obj.untyped_storage()
             out.setdefault(st.data_ptr(), (path, obj))
-        for a in ("_ff_split", "_ff_halo", "_ff_quad"):
+        for a in ("_ff_split", "_ff_halo", "_ff_quad", "_ff_small"):
             if hasattr(obj, a):
                 _walk_tensors(getattr(obj, a), f"{path}.{a}", out, seen)
         return

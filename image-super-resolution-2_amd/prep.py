@@ -238,3 +238,16 @@ def pack_token_linear_gated(w: T, b: Optional[T], gw1: T, gb1: Optional[T], gw2:
     g2 = torch.zeros(32, device=w.device)
     g2[:hd] = gw2.reshape(-1)
     return dict(nt=nt, K=K, N=N, w=torch.stack([hi, lo], dim=1).contiguous(), b=bp, gb1=g1, gw2=g2)
+
+
+def small_ct(cout: int) -> int:
+    return 1 if cout == 1 else (4 if cout <= 4 else 16)
+
+
+def pack_conv3x3_small(wp: T, cin: int) -> T:
+    """Weight image of ff_conv3x3_small from a packed 3x3 weight [Cout, 9*cin] (tap-major, pack_conv): fp32 [9][ceil4(cin)][CT]."""
+    cout = wp.shape[0]
+    ct, cp = small_ct(cout), (cin + 3) // 4 * 4
+    w = torch.zeros(9, cp, ct, device=wp.device)
+    w[:, :cin, :cout] = wp.reshape(cout, 9, cin).permute(1, 2, 0)
+    return w.contiguous()

@@ -57,6 +57,13 @@ int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_lo, int Kp,
                     int nterms, int tile_hint, void* stream);
 int ff_split_bf16(const float* w, int N, int K, int Kp, int Cin, int Cp, void* hi, void* lo, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution for small channel counts (csrc/conv3x3_small.hip): Cin <= 64, Cout <= 16, exact fp32 on
+ * the VALU, out = res + alpha * act(conv(in) + bias).  w_small: fp32 [9][ceil4(Cin)][CT], CT = 1 / 4 / 16 >= Cout, zero padded
+ * (prep.pack_conv3x3_small).  Replaces the tail convolutions of the fusion stack at 1024 x 1024: to_rgb (hierarchical_fusion.py:
+ * 124-128), refine_net.6 (enhanced_fusion.py:288), the edge fusion / gate convolutions (edge_enhancement.py:112,170-180). */
+int ff_conv3x3_small(const float* in, int ldi, const float* w_small, int ct, const float* bias, const float* res, int ldr,
+                     float* out, int ldo, int B, int H, int W, int Cin, int Cout, int act, float alpha, void* stream);
+
 
 /* Fused window attention softmax((q*scale) k^T + bias (+mask)) v on fp32 MFMA; one workgroup per
  * (window, head).  qkv is the token tensor [B][H][W][ldq]; q/k/v of head h live at *_off + h*d.

@@ -834,3 +834,30 @@ def test_dwconv_large_kernels_at_bench_size(dev, kh, kw):
     ref = F.conv2d(x, w, None, padding=(kh // 2, kw // 2), groups=C)
     out = ops.dwconv2d(x.permute(0, 2, 3, 1).contiguous(), pack_dw(w), None, ksize=(kh, kw), pad=(kh // 2, kw // 2))
     close(out.permute(0, 3, 1, 2), ref, 1e-5, "dwconv large kernel")
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,act,with_res", [(64, 3, 1024, 1024, None, True), (32, 16, 256, 260, "gelu", False), (16, 3, 100, 75, "sigmoid", False),
+                                                       (8, 1, 128, 128, "sigmoid", False), (6, 16, 96, 64, "gelu", False), (27, 9, 64, 64, "sigmoid", False)])
+def test_conv3x3_small_matches_torch(dev, Cin, Cout, H, W, act, with_res):
+    """fp32 VALU 3x3 convolution for small channel counts (the fusion stack's tail layers) against torch fp32, incl. ragged tiles,
+    unaligned Cin (6, 27), residual + alpha, strided input slices."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_conv
+    prev = ops.gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        wide = rnd(1, H, W, Cin + 4, dev=dev, seed=920)
+        x = wide[..., :Cin]
+        w = rnd(Cout, Cin, 3, 3, dev=dev, seed=921, scale=1.0 / math.sqrt(9 * Cin))
+        b = rnd(Cout, dev=dev, seed=922, scale=0.1)
+        res = rnd(1, H, W, Cout, dev=dev, seed=923) if with_res else None
+        f = {"gelu": F.gelu, "sigmoid": torch.sigmoid, None: lambda t: t}[act]
+        ref = f(F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)).permute(0, 2, 3, 1) * 0.1
+        if with_res:
+            ref = ref + res
+        wp = pack_conv(w)
+        out = ops.conv2d(x, wp, b, ksize=(3, 3), pad=(1, 1), act=act, res=res, alpha=0.1)
+        assert getattr(wp, "_ff_small", None) is not None, "small-channel kernel was not selected"
+        close(out, ref, 3e-6, "conv3x3 small")
+    finally:
+        ops.set_gemm_mode(prev)
