@@ -119,6 +119,16 @@ class CrossBandLKA:
         self.scale1, self.scale2 = float(sdd[q + ".scale1"].cpu()), float(sdd[q + ".scale2"].cpu())
         self.ffn0 = _lin1x1(sd, q + ".ffn.0", dev)
         self.ffn2 = _lin1x1(sd, q + ".ffn.2", dev)
+        # token-stationary forms (split-bf16 modes): the eval BatchNorm in front of the FFN is a per-channel affine and folds into
+        # ffn.0 (W (s*x + t) + b = (W diag s) x + (W t + b)); scale2 folds into ffn.2; norm + in_proj and out_proj + residual are
+        # ff_token_linear launches with the LayerNorm in the prologue -- three bandwidth passes over the 151 MB token matrix fewer
+        from .prep import pack_token_linear
+        w0, b0 = self.ffn0
+        self.tl_ffn0 = pack_token_linear((w0 * s2[None, :]).contiguous(), (b0 + w0 @ t2).contiguous())
+        w2, b2 = self.ffn2
+        self.tl_ffn2 = pack_token_linear((w2 * self.scale2).contiguous(), (b2 * self.scale2).contiguous())
+        self.tl_in = pack_token_linear(*self.in_proj)
+        self.tl_out = pack_token_linear(*self.out_proj)
         self.outp = _lin1x1(sd, p + ".out_proj", dev)
 
     def __call__(self, bands: T) -> T:
@@ -130,10 +140,13 @@ class CrossBandLKA:
         for i in range(nb):
             ops.linear(bands[..., 3 * i:3 * i + 3], *self.proj, out=tok[..., E * i:E * (i + 1)])
         rows = tok.reshape(P * nb, E)                                   # token (pixel, band) rows
-        tn = ops.layernorm(rows, *self.norm)
-        qkv = ops.linear(tn, *self.in_proj)
+        fast = ops.gemm_mode() == "bf16x3"
+        if fast:
+            qkv = ops.token_linear(rows, self.tl_in, gamma=self.norm[0], beta=self.norm[1])          # LayerNorm + in_proj
+        else:
+            qkv = ops.linear(ops.layernorm(rows, *self.norm), *self.in_proj)
         att = ops.band_mha_core(qkv, P, nb, self.heads)
-        x = ops.linear(att, *self.out_proj, res=rows)                   # [9P, 64]
+        x = ops.token_linear(att, self.tl_out, res=rows) if fast else ops.linear(att, *self.out_proj, res=rows)      # [9P, 64]
         ximg = x.reshape(1, H, W, nb * E)
         # LKA block on all bands at once
         t = ops.affine(ximg, *self.bn1)
@@ -142,9 +155,13 @@ class CrossBandLKA:
         a = ops.dwconv2d(a, self.dwv, None, ksize=(21, 1), pad=(10, 0))
         a = ops.linear(a.reshape(P * nb, E), *self.pw, act="sigmoid")
         x = ops.fma3(x, t.reshape(P * nb, E), a, self.scale1)           # x + s1 * (norm1(x) * attn)
-        t2 = ops.affine(x, *self.bn2)
-        f = ops.linear(t2, *self.ffn0, act="gelu")
-        x = ops.linear(f, *self.ffn2, res=x, alpha=self.scale2)
+        if fast:
+            f = ops.token_linear(x, self.tl_ffn0, act="gelu")           # BatchNorm folded in
+            x = ops.token_linear(f, self.tl_ffn2, res=x)                # scale2 folded in
+        else:
+            t2 = ops.affine(x, *self.bn2)
+            f = ops.linear(t2, *self.ffn0, act="gelu")
+            x = ops.linear(f, *self.ffn2, res=x, alpha=self.scale2)
         ximg = x.reshape(1, H, W, nb * E)
         out = torch.empty_like(bands)
         for i in range(nb):

@@ -211,8 +211,10 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
             raise _lib.FFError(f"conv2d: res shape {tuple(res.shape)} != {oshape}")
         rp, ldr, *_ = _nhwc(res, "conv2d.res")
     if (_SMALL and _GEMM_MODE != "f32" and (KH, KW) == (3, 3) and tuple(stride) == (1, 1) and tuple(pad) == (1, 1) and Cout <= 16
-            and Cin <= 64 and shuffle == 0 and mul is None and not dynamic_w and H * W >= 4096 and xp != op):
-        # small-channel tail convolutions: exact fp32 on the VALU from an LDS halo tile (csrc/conv3x3_small.hip)
+            and Cin * (1 if Cout == 1 else (4 if Cout <= 4 else 16)) <= 128 and shuffle == 0 and mul is None and not dynamic_w and H * W >= 4096 and xp != op):
+        # small-channel tail convolutions: exact fp32 on the VALU from an LDS halo tile (csrc/conv3x3_small.hip).  Measured on
+        # MI355X at 1024 x 1024: 16->3 205 -> <70 us, 8->1 160 -> <70, 16->1 204 -> <70, 32->3 166 -> 95, 6->16 173 -> 126; but
+        # 64->3 202 -> 370 and 32->16 187 -> 199 (VALU-bound: Cin * CT FMAs per pixel and tap), hence the Cin * CT <= 128 rule
         ws = getattr(w, "_ff_small", None)
         if ws is None:
             from . import prep as _prep
