@@ -308,11 +308,45 @@ __global__ __launch_bounds__(256) void pixel_mlp_kernel(const float* __restrict_
   }
 }
 
+// C <= 64: one LANE per pixel (the 16-lanes-per-pixel form above leaves 8 of 16 lanes idle at C = 32 and ran the hierarchical
+// fusion's SpatialGate at 0.9 TB/s): a lane reads its pixel's whole row (consecutive lanes = consecutive rows: coalesced when
+// the rows are dense), the weights are wave-uniform scalar loads.
+template <int C4>
+__global__ __launch_bounds__(256) void pixel_mlp_lane_kernel(const float* __restrict__ in, int ldi, long long P, int Hd,
+                                                             const float* __restrict__ W1, const float* __restrict__ b1, int act1,
+                                                             const float* __restrict__ w2, float b2, int act2, float* __restrict__ out) {
+  for (long long pp = (long long)blockIdx.x * 256 + threadIdx.x; pp < P; pp += (long long)gridDim.x * 256) {
+    f32x4 x[C4];
+#pragma unroll
+    for (int k = 0; k < C4; ++k) x[k] = *reinterpret_cast<const f32x4*>(in + pp * ldi + 4 * k);
+    float o = b2;
+    for (int j = 0; j < Hd; ++j) {
+      const float* wr = W1 + j * (4 * C4);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < C4; ++k) {
+        s0 = __builtin_fmaf(x[k][0], wr[4 * k], s0); s1 = __builtin_fmaf(x[k][1], wr[4 * k + 1], s1);
+        s0 = __builtin_fmaf(x[k][2], wr[4 * k + 2], s0); s1 = __builtin_fmaf(x[k][3], wr[4 * k + 3], s1);
+      }
+      o = __builtin_fmaf(w2[j], ff_act_fast(s0 + s1 + (b1 ? b1[j] : 0.f), act1), o);
+    }
+    out[pp] = ff_act(o, act2);
+  }
+}
+
 extern "C" int ff_pixel_mlp(const float* in, int ldi, long long P, int C, int hidden, const float* W1, const float* b1, int act1,
                             const float* w2, float b2, int act2, float* out, void* stream) {
   FF_CHECK_ARG(in && W1 && w2 && out, "ff_pixel_mlp: null pointer");
   FF_CHECK_ARG(P > 0 && C > 0 && C <= 192 && C % 4 == 0 && ldi >= C && ldi % 4 == 0 && (((uintptr_t)in) & 15) == 0, "ff_pixel_mlp: needs C <= 192, C %% 4 == 0, 16-byte aligned rows");
   FF_CHECK_ARG(hidden > 0 && hidden <= PM_MAXH, "ff_pixel_mlp: hidden width must be 1..16");
+  if (C == 32 || C == 64) {
+    long long nbl = (P + 255) / 256;
+    if (nbl > 16384) nbl = 16384;
+    if (C == 32) hipLaunchKernelGGL(pixel_mlp_lane_kernel<8>, dim3((unsigned)nbl), dim3(256), 0, (hipStream_t)stream, in, ldi, P, hidden, W1, b1, act1, w2, b2, act2, out);
+    else hipLaunchKernelGGL(pixel_mlp_lane_kernel<16>, dim3((unsigned)nbl), dim3(256), 0, (hipStream_t)stream, in, ldi, P, hidden, W1, b1, act1, w2, b2, act2, out);
+    FF_LAUNCH_CHECK("ff_pixel_mlp");
+    return FF_OK;
+  }
   long long nb = (P + 63) / 64;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(pixel_mlp_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, ldi, P, C, hidden, W1, b1, act1, w2, b2, act2, out);

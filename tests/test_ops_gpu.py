@@ -349,7 +349,7 @@ def test_window_attn_dat_branches(dev, gemm_mode, H, W, shifted):
         close(out[..., br * half:(br + 1) * half], o[:, :H, :W], GEMM_TOL[gemm_mode], f"dat branch {br}")
 
 
-@pytest.mark.parametrize("P,C,Hd", [(65536, 180, 11), (1000, 64, 16), (77, 192, 3)])
+@pytest.mark.parametrize("P,C,Hd", [(65536, 180, 11), (1000, 64, 16), (77, 192, 3), (1048576, 32, 8), (5000, 64, 16)])
 def test_pixel_mlp(dev, P, C, Hd):
     """DAT spatial-interaction gate (dat_arch.py:585-590) as one per-pixel kernel against the PyTorch chain."""
     from isr2_amd import ops
