@@ -27,7 +27,7 @@ struct HaloParams {
 // WK = input channels per weight tile (64: one tile per (chunk, tap); 32: two).  The 192-channel configuration uses
 // 16x16-pixel workgroups (weights are re-streamed per workgroup: 256 pixels per fetch halve the L2 traffic that bounds
 // the 128-pixel form) and 32-channel weight tiles so that the 88 KB input tile and the ring still fit in 160 KB.
-template <int WM, int WN, int MI, int NI, int WK, int ACT>
+template <int WM, int WN, int MI, int NI, int WK, int ACT, int NSLOT>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p) {
   constexpr int NW = WM * WN, NT = NW * 64;            // 4 or 8 waves
   static_assert(NW == 4 || NW == 8, "four or eight waves");
@@ -69,7 +69,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
     }
   };
   const int ntiles = p.nchunk * 9 * NH;
+  // Ring depth: NSLOT = 3 issues the tile for tap T+2 while tap T computes and lets the (younger) pieces of tile T+1 stay in flight
+  // at the top of tap T (s_waitcnt vmcnt(NPMIN), NPMIN = the fewest pieces any wave issues per tile; over-waiting by one piece on the
+  // other waves is safe: vmcnt retires in issue order).  Measured in round 2: no gain over two slots (CAB 180->60: 54.5 vs 53.2 us; the
+  // weight tiles are L2 hits that land within a tap's MFMAs) and slower for the 32-channel form, so every configuration launches NSLOT = 2.
+  constexpr int NPMIN = WPIECES / NW;
   dma(0, 0);
+  if (NSLOT > 2 && ntiles > 1) dma(1, 1);
 
   // ---- input halo staging: 16 lanes (float4 each) per pixel, 16 pixels per pass ---------------------------------
   const int cq = (tid & 15) * 4, prow = tid >> 4;
@@ -139,11 +145,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
       for (int half = 0; half < NH; ++half, ++T) {
         // own DMA pieces of tile T (and any prefetched input rows) have landed; the barrier then makes every wave's
         // pieces and the staged input tile visible, and guarantees slot (T+1)&1 is no longer being read
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NSLOT > 2 && NPMIN > 0 && T + 1 < ntiles) {
+          if (NPMIN == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          else if (NPMIN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
-        if (T + 1 < ntiles) dma(T + 1, (T + 1) & 1);
+        if (NSLOT > 2) { if (T + 2 < ntiles) dma(T + 2, (T + 2) % NSLOT); }
+        else if (T + 1 < ntiles) dma(T + 1, (T + 1) & 1);
         if (XPREF && tap == 7 && half == NH - 1 && chunk + 1 < p.nchunk) load_x(chunk + 1);
-        const unsigned char* wb = Ws + (T & 1) * WSLOT;
+        const unsigned char* wb = Ws + (T % NSLOT) * WSLOT;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
           bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
@@ -250,11 +263,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
   }
 }
 
-template <int WM, int WN, int MI, int NI, int WK>
+template <int WM, int WN, int MI, int NI, int WK, int NSLOT>
 static int launch_halo(HaloParams& p, hipStream_t st) {
   constexpr int TH = WM * MI * 2, NPX = (TH + 2) * HX_W, BN = WN * NI * 32;
   constexpr int WSLOT = ((BN * (WK * 4 + 16) + 1023) / 1024) * 1024;
-  constexpr size_t lds = (size_t)NPX * HX_ROW + 2 * WSLOT;
+  constexpr size_t lds = (size_t)NPX * HX_ROW + NSLOT * WSLOT;
   static_assert(lds <= 160 * 1024, "LDS budget");
   p.tiles_x = (p.W + 15) / 16;
   p.tiles_y = (p.H + TH - 1) / TH;
@@ -266,12 +279,12 @@ static int launch_halo(HaloParams& p, hipStream_t st) {
     constexpr int ACT = decltype(A)::value;
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, MI, NI, WK, ACT>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, MI, NI, WK, ACT, NSLOT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { ff_set_error("ff_conv3x3_halo: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); attr_failed = true; return; }
       attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, MI, NI, WK, ACT>), dim3((unsigned)nblocks), dim3(WM * WN * 64), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, MI, NI, WK, ACT, NSLOT>), dim3((unsigned)nblocks), dim3(WM * WN * 64), lds, st, p);
   };
   FF_DISPATCH_ACT(p.act, go);
   if (attr_failed) return FF_ERR_LAUNCH;
@@ -314,10 +327,10 @@ extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int 
   switch (bn) {
     // 16x16-pixel workgroups of 8 waves (two per SIMD: one wave's LDS reads and waits hide behind the
     // other's MFMAs -- measured 140 -> 121 us for 180->180 against the 4-wave form)
-    case 32: return launch_halo<8, 1, 1, 1, 64>(p, st);    // wave: 32 pixels x 32 channels
-    case 64: return launch_halo<8, 1, 1, 2, 64>(p, st);    // wave: 32 pixels x 64
-    case 128: return launch_halo<2, 2, 2, 2, 64>(p, st);   // 8x16 pixels, 4 waves (only the two up-sampling convolutions use it)
-    case 192: return launch_halo<4, 2, 2, 3, 32>(p, st);   // 16x16 pixels x 192, 8 waves (2 per SIMD), 32-channel weight tiles
+    case 32: return launch_halo<8, 1, 1, 1, 64, 2>(p, st);    // wave: 32 pixels x 32 channels
+    case 64: return launch_halo<8, 1, 1, 2, 64, 2>(p, st);    // wave: 32 pixels x 64
+    case 128: return launch_halo<2, 2, 2, 2, 64, 2>(p, st);   // 8x16 pixels, 4 waves (only the two up-sampling convolutions use it)
+    case 192: return launch_halo<4, 2, 2, 3, 32, 2>(p, st);   // 16x16 pixels x 192, 8 waves (2 per SIMD), 32-channel weight tiles; 88 KB tile + 2 x 27 KB ring
     default: ff_set_error("ff_conv3x3_halo: bn must be 32, 64, 128 or 192"); return FF_ERR_ARG;
   }
 }
