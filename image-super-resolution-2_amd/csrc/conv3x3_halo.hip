@@ -23,6 +23,10 @@ struct HaloParams {
 
 #define HX_ROW 272
 #define HX_W 18
+// Bytes per halo-tile ROW of 18 pixels, padded to 1280 dwords == 0 (mod 64 banks): a 32-pixel m-tile is two pixel rows, and
+// ds_read_b128 services lanes {0-3, 12-15, 20-27} together -- with the natural pitch (18 x 68 = 1224 dwords == 8 mod 64) the second
+// row's lanes landed on banks the first row's lanes 12-15 use (SQ_LDS_BANK_CONFLICT = 23 % of the LDS cycles, round 2).
+#define HX_PROW 5120
 
 // WK = input channels per weight tile (64: one tile per (chunk, tap); 32: two).  The 192-channel configuration uses
 // 16x16-pixel workgroups (weights are re-streamed per workgroup: 256 pixels per fetch halve the L2 traffic that bounds
@@ -34,7 +38,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
   constexpr int PPP = NT / 16;                         // pixels staged per pass (16 lanes per pixel)
   constexpr int TH = WM * MI * 2, NPX = (TH + 2) * HX_W, NPASS = (NPX + PPP - 1) / PPP;
   constexpr int BN = WN * NI * 32, TN = NI * 32;
-  constexpr int XBYTES = NPX * HX_ROW;
+  constexpr int XBYTES = (TH + 2) * HX_PROW;
   constexpr int WROW = WK * 4 + 16, NH = 64 / WK, KSTEPS = WK / 16;
   constexpr bool XPREF = MI * NI <= 6;        // prefetch the next chunk's input rows into registers during tap 7
   constexpr int WPIECES = (BN * WROW + 1023) / 1024, WSLOT = WPIECES * 1024;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
         lo[e] = (__bf16)(f - (float)h);
       }
       if (hp < NPX) {
-        unsigned char* dst = Xs + hp * HX_ROW + (tid & 15) * 8;
+        unsigned char* dst = Xs + (hp / HX_W) * HX_PROW + (hp % HX_W) * HX_ROW + (tid & 15) * 8;
         *reinterpret_cast<bf16x4*>(dst) = hi;
         *reinterpret_cast<bf16x4*>(dst + 128) = lo;
       }
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
   // per-lane LDS byte offsets (tap (0,0)): pixel row of m-tile i, weight row of n-tile j
   int aoff[MI], boff[NI];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) aoff[i] = (((wr * MI + i) * 2 + (l31 >> 4)) * HX_W + (l31 & 15)) * HX_ROW + 16 * hh;
+  for (int i = 0; i < MI; ++i) aoff[i] = ((wr * MI + i) * 2 + (l31 >> 4)) * HX_PROW + (l31 & 15) * HX_ROW + 16 * hh;
 #pragma unroll
   for (int j = 0; j < NI; ++j) boff[j] = (wc * TN + j * 32 + l31) * WROW + 16 * hh;
 
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap - 3 * dy;
-      const unsigned char* xa = Xs + (dy * HX_W + dx) * HX_ROW;
+      const unsigned char* xa = Xs + dy * HX_PROW + dx * HX_ROW;
 #pragma unroll
       for (int half = 0; half < NH; ++half, ++T) {
         // own DMA pieces of tile T (and any prefetched input rows) have landed; the barrier then makes every wave's
@@ -265,9 +269,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
 
 template <int WM, int WN, int MI, int NI, int WK, int NSLOT>
 static int launch_halo(HaloParams& p, hipStream_t st) {
-  constexpr int TH = WM * MI * 2, NPX = (TH + 2) * HX_W, BN = WN * NI * 32;
+  constexpr int TH = WM * MI * 2, BN = WN * NI * 32;
   constexpr int WSLOT = ((BN * (WK * 4 + 16) + 1023) / 1024) * 1024;
-  constexpr size_t lds = (size_t)NPX * HX_ROW + NSLOT * WSLOT;
+  constexpr size_t lds = (size_t)(TH + 2) * HX_PROW + NSLOT * WSLOT;
   static_assert(lds <= 160 * 1024, "LDS budget");
   p.tiles_x = (p.W + 15) / 16;
   p.tiles_y = (p.H + TH - 1) / TH;
