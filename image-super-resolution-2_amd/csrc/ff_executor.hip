@@ -18,7 +18,7 @@ union FFVal { long long i; double f; void* p; };
 enum { K_INT = 0, K_FLT, K_NULL, K_WEIGHT, K_WORK, K_INPUT, K_OUTPUT, K_STREAM };
 
 struct PlanArg { uint8_t kind; long long a, b; double f; };
-struct PlanCall { int fn; int first, n; };
+struct PlanCall { int fn; int first, n; int stream; };      // fn == -1: fork (stream 0) / join (stream 1) marker
 struct PlanSlot { std::string name; long long nbytes; void* dev; bool filled; };
 struct ff_model {
   std::vector<PlanSlot> slots;
@@ -28,6 +28,10 @@ struct ff_model {
   void* work = nullptr;
   int in[4], out[4];
   bool finalized = false;
+  // the host's three-stream schedule: between a fork and a join marker the launches of stream 1 / 2 go to two internal streams
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  int nstreams = 1;
 };
 
 static bool rd(FILE* f, void* dst, size_t n) { return fread(dst, 1, n, f) == n; }
@@ -36,6 +40,8 @@ static void free_model(ff_model* m) {
   if (!m) return;
   for (auto& s : m->slots) if (s.dev) (void)hipFree(s.dev);
   if (m->work) (void)hipFree(m->work);
+  for (int i = 0; i < 2; ++i) { if (m->side[i]) (void)hipStreamDestroy(m->side[i]); if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]); }
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
   delete m;
 }
 
@@ -48,7 +54,7 @@ extern "C" int ff_create(const char* plan_path, void** out_handle) {
   auto fail = [&](const char* why) { ff_set_error("ff_create: %s: %s", plan_path, why); fclose(f); free_model(m); return FF_ERR_ARG; };
   char magic[8];
   int32_t abi; uint32_t nnames;
-  if (!rd(f, magic, 8) || memcmp(magic, "FFPLAN2\0", 8) != 0) return fail("not an FFPLAN2 file");
+  if (!rd(f, magic, 8) || memcmp(magic, "FFPLAN3\0", 8) != 0) return fail("not an FFPLAN3 file");
   if (!rd(f, &abi, 4) || !rd(f, &nnames, 4) || nnames > 4096) return fail("truncated header");
   if (abi != ff_abi_version()) return fail("plan was recorded against another ABI version of the kernel library");
   std::vector<int> fnmap(nnames, -1);
@@ -76,9 +82,12 @@ extern "C" int ff_create(const char* plan_path, void** out_handle) {
   if (!rd(f, &ncalls, 4) || ncalls > (1u << 24)) return fail("bad call count");
   m->calls.resize(ncalls);
   for (auto& c : m->calls) {
-    uint16_t fid, na;
-    if (!rd(f, &fid, 2) || !rd(f, &na, 2) || fid >= nnames || na > 64) return fail("bad call record");
-    c.fn = fnmap[fid]; c.first = (int)m->args.size(); c.n = na;
+    uint16_t fid, na, sid;
+    if (!rd(f, &fid, 2) || !rd(f, &na, 2) || !rd(f, &sid, 2)) return fail("bad call record");
+    if (fid == 0xFFFF) { c.fn = -1; c.first = 0; c.n = 0; c.stream = sid; if (sid > 1) return fail("bad marker"); continue; }
+    if (fid >= nnames || na > 64 || sid > 2) return fail("bad call record");
+    c.fn = fnmap[fid]; c.first = (int)m->args.size(); c.n = na; c.stream = sid;
+    if (sid + 1 > m->nstreams) m->nstreams = sid + 1;
     for (int i = 0; i < na; ++i) {
       unsigned char rec[20];
       if (!rd(f, rec, 20)) return fail("truncated arguments");
@@ -95,6 +104,12 @@ extern "C" int ff_create(const char* plan_path, void** out_handle) {
   for (auto& s : m->slots)
     if (hipMalloc(&s.dev, (size_t)(s.nbytes > 0 ? s.nbytes : 1)) != hipSuccess) { ff_set_error("ff_create: hipMalloc of slot %s (%lld bytes) failed", s.name.c_str(), s.nbytes); free_model(m); return FF_ERR_LAUNCH; }
   if (hipMalloc(&m->work, (size_t)(m->wbytes > 0 ? m->wbytes : 1)) != hipSuccess) { ff_set_error("ff_create: hipMalloc of the %lld-byte workspace failed", m->wbytes); free_model(m); return FF_ERR_LAUNCH; }
+  if (m->nstreams > 1) {
+    bool ok = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i)
+      ok = hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { ff_set_error("ff_create: cannot create the executor's streams / events"); free_model(m); return FF_ERR_LAUNCH; }
+  }
   *out_handle = m;
   return FF_OK;
 }
@@ -127,7 +142,23 @@ extern "C" int ff_forward(void* handle, const float* lr_dev, int B, int H, int W
   FF_CHECK_ARG(m->finalized, "ff_forward: ff_finalize has not succeeded on this handle");
   FF_CHECK_ARG(B == m->in[0] && H == m->in[2] && W == m->in[3], "ff_forward: this plan is for input [%d,3,%d,%d], got [%d,3,%d,%d]", m->in[0], m->in[2], m->in[3], B, H, W);
   FFVal v[64];
+  hipStream_t main_st = (hipStream_t)stream;
   for (const PlanCall& c : m->calls) {
+    if (c.fn < 0) {
+      if (m->nstreams > 1) {
+        bool ok = true;
+        if (c.stream == 0) {                                 // fork: the side streams wait for everything issued on the caller's stream so far
+          ok = hipEventRecord(m->ev_fork, main_st) == hipSuccess;
+          for (int i = 0; i < 2 && ok; ++i) ok = hipStreamWaitEvent(m->side[i], m->ev_fork, 0) == hipSuccess;
+        } else {                                             // join: the caller's stream waits for both side streams
+          for (int i = 0; i < 2 && ok; ++i)
+            ok = hipEventRecord(m->ev_join[i], m->side[i]) == hipSuccess && hipStreamWaitEvent(main_st, m->ev_join[i], 0) == hipSuccess;
+        }
+        if (!ok) { ff_set_error("ff_forward: stream fork / join failed: %s", hipGetErrorString(hipGetLastError())); return FF_ERR_LAUNCH; }
+      }
+      continue;
+    }
+    void* call_stream = (c.stream == 0 || m->nstreams == 1) ? stream : (void*)m->side[c.stream - 1];
     for (int i = 0; i < c.n; ++i) {
       const PlanArg& a = m->args[c.first + i];
       switch (a.kind) {
@@ -138,7 +169,7 @@ extern "C" int ff_forward(void* handle, const float* lr_dev, int B, int H, int W
         case K_WORK: v[i].p = (char*)m->work + a.b; break;
         case K_INPUT: v[i].p = (char*)lr_dev + a.b; break;
         case K_OUTPUT: v[i].p = (char*)out_dev + a.b; break;
-        default: v[i].p = stream; break;
+        default: v[i].p = call_stream; break;
       }
     }
     const int rc = ff_dispatch(c.fn, v);

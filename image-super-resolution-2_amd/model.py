@@ -31,6 +31,7 @@ class FreqFusionHIP:
         self.dev = dev
         self.multi_stream = os.environ.get("FF_STREAMS", "1") != "0"
         self._side = None
+        self._marker = None                              # plan recording: called with "fork" / "join" around the three-stream section
         self._graphs = {}                                # (B,h,w) -> (graph, static input, static output)
         self.max_graphs = int(os.environ.get("FF_MAX_GRAPHS", "6"))
         with torch.cuda.device(dev):
@@ -53,6 +54,8 @@ class FreqFusionHIP:
         s1, s2 = self._side
         s1.wait_stream(main)
         s2.wait_stream(main)
+        if self._marker:
+            self._marker("fork")
         pre = None
         with torch.cuda.stream(s1):
             dat = self.dat.forward(lr)
@@ -63,6 +66,8 @@ class FreqFusionHIP:
         hat = self.hat.forward(lr)
         main.wait_stream(s1)
         main.wait_stream(s2)
+        if self._marker:
+            self._marker("join")
         dat.record_stream(main)
         naf.record_stream(main)
         if pre is not None:

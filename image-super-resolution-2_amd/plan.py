@@ -26,7 +26,8 @@ import torch
 
 from . import lib as _lib
 
-MAGIC_PLAN, MAGIC_WTS = b"FFPLAN2\0", b"FFWTS01\0"
+MAGIC_PLAN, MAGIC_WTS = b"FFPLAN3\0", b"FFWTS01\0"
+FID_MARK = 0xFFFF
 K_INT, K_FLT, K_NULL, K_WEIGHT, K_WORK, K_INPUT, K_OUTPUT, K_STREAM = range(8)
 _PTR_TYPES = ("const float*", "float*", "void*", "const void*", "const unsigned char*", "unsigned char*", "double*", "const double*")
 ALIGN = 256
@@ -84,13 +85,14 @@ class _Recorder:
     def __init__(self, real, protos):
         self.real, self.protos = real, protos
         self.iv = _Intervals()
-        self.calls: List[Tuple[str, list]] = []
-        self.work: List[List[int]] = []                         # per activation buffer: [nbytes, first_call, last_call]
+        self.calls: List[Tuple[str, list, int]] = []            # (entry point | "fork" | "join", args, stream index)
+        self.work: List[list] = []                              # per activation buffer: [nbytes, first_call, last_call, {streams}]
+        self.streams: Dict[int, int] = {}                       # hipStream_t value -> index (0 = the caller's stream)
 
     def note_alloc(self, t: torch.Tensor):
         if isinstance(t, torch.Tensor) and t.is_cuda:
             st = t.untyped_storage()
-            self.work.append([st.nbytes(), -1, -1])
+            self.work.append([st.nbytes(), -1, -1, set()])
             self.iv.add(st.data_ptr(), st.nbytes(), K_WORK, len(self.work) - 1)
 
     def __getattr__(self, name):
@@ -100,6 +102,7 @@ class _Recorder:
             return fn
 
         def wrapped(*args):
+            sidx = self.streams.setdefault(int(args[-1] or 0), len(self.streams))
             enc = []
             for a, ty in zip(args[:-1], proto[1][:-1]):
                 if ty in _PTR_TYPES:
@@ -115,46 +118,64 @@ class _Recorder:
                         w = self.work[ident]
                         w[1] = len(self.calls) if w[1] < 0 else w[1]
                         w[2] = len(self.calls)
+                        w[3].add(sidx)
                     enc.append((kind, ident, off))
                 elif ty in ("float", "double"):
                     enc.append((K_FLT, float(a), 0))
                 else:
                     enc.append((K_INT, int(a), 0))
             enc.append((K_STREAM, 0, 0))
-            self.calls.append((name, enc))
+            self.calls.append((name, enc, sidx))
             return fn(*args)
         return wrapped
 
+    def mark(self, what: str):
+        self.calls.append((what, [], 0))
 
-def _pack_offsets(work: List[List[int]]) -> Tuple[List[int], int]:
-    """Workspace offsets by lifetime: buffers whose [first, last] launch intervals overlap never share bytes.  Greedy by
-    decreasing size, lowest fitting offset."""
+
+def _pack_offsets(work: List[list], regions: List[Tuple[int, int]] = ()) -> Tuple[List[int], int]:
+    """Workspace offsets by lifetime: buffers whose [first, last] launch intervals overlap never share bytes; inside a fork..join
+    region (launch indices) the streams run concurrently, so two buffers touched there by DIFFERENT streams never share bytes
+    either, whatever their tape order.  Greedy by decreasing size, lowest fitting offset."""
+    def in_region(w):
+        return any(not (w[2] < a or w[1] > b) for a, b in regions)
+
     order = sorted((i for i, w in enumerate(work) if w[1] >= 0), key=lambda i: -work[i][0])
-    placed: List[Tuple[int, int, int, int]] = []                # (offset, end, first, last)
+    placed: List[Tuple[int, int, int]] = []                     # (offset, end, buffer index)
     offs = [0] * len(work)
     total = 0
+    reg = {i: in_region(work[i]) for i in order}
     for i in order:
         size = (work[i][0] + ALIGN - 1) // ALIGN * ALIGN
         f, l = work[i][1], work[i][2]
-        busy = sorted((o, e) for o, e, pf, pl in placed if not (pl < f or pf > l))
+        si = work[i][3] if len(work[i]) > 3 else {0}
+        busy = []
+        for o, e, j in placed:
+            wj = work[j]
+            sj = wj[3] if len(wj) > 3 else {0}
+            if not (wj[2] < f or wj[1] > l) or (reg[i] and reg[j] and (si != sj or len(si) > 1)):
+                busy.append((o, e))
+        busy.sort()
         cur = 0
         for o, e in busy:
             if o - cur >= size:
                 break
             cur = max(cur, e)
         offs[i] = cur
-        placed.append((cur, cur + size, f, l))
+        placed.append((cur, cur + size, i))
         total = max(total, cur + size)
     return offs, total
 
 
 @torch.no_grad()
-def export_plan(model, lr: torch.Tensor, stem: str) -> dict:
-    """Record model.forward(lr) (single stream) and write <stem>.ffplan / <stem>.ffwts.  Returns a summary dict."""
+def export_plan(model, lr: torch.Tensor, stem: str, multi_stream: bool = True) -> dict:
+    """Record model.forward(lr) and write <stem>.ffplan / <stem>.ffwts.  multi_stream: keep the host's three-stream schedule
+    (the experts side by side between a fork and a join marker; the executor replays them on two internal streams).
+    Returns a summary dict."""
     dev = model.dev
     lr = lr.to(dev, torch.float32).contiguous()
     ms = model.multi_stream
-    model.multi_stream = False
+    model.multi_stream = bool(multi_stream)
     try:
         ref = model.forward(lr).clone()                             # also runs every lazy weight preparation
         torch.cuda.synchronize(dev)
@@ -183,9 +204,12 @@ def export_plan(model, lr: torch.Tensor, stem: str) -> dict:
         for n, fn in orig.items():
             setattr(torch, n, hook(fn))
         _lib._lib = rec
+        model._marker = rec.mark
+        rec.streams[int(torch.cuda.current_stream(dev).cuda_stream)] = 0
         try:
             out = model.forward(lr)
         finally:
+            model._marker = None
             _lib._lib = real
             for n, fn in orig.items():
                 setattr(torch, n, fn)
@@ -200,10 +224,34 @@ def export_plan(model, lr: torch.Tensor, stem: str) -> dict:
     if hit is None or hit[0] != K_WORK or hit[2] != 0:
         raise _lib.FFError("plan recording: the output tensor is not a fresh allocation")
     out_buf = hit[1]
-    offs, wbytes = _pack_offsets([w if i != out_buf else [0, -1, -1] for i, w in enumerate(rec.work)])
-    used_slots = sorted({e[1] for _, enc in rec.calls for e in enc if e[0] == K_WEIGHT})
+    regions, start = [], None
+    for i, (n, _, _) in enumerate(rec.calls):
+        if n == "fork":
+            start = i
+        elif n == "join" and start is not None:
+            regions.append((start, i))
+            start = None
+    offs, wbytes = _pack_offsets([w if i != out_buf else [0, -1, -1, set()] for i, w in enumerate(rec.work)], regions)
+    # The host issues one expert after the other inside a region; an eager (un-captured) replay would reach the last stream's
+    # first launch only after queueing everything else.  Interleave the region's launches across its streams in proportion
+    # (order within a stream kept, so the lifetimes used for the packing above still hold).
+    calls = list(rec.calls)
+    for a, b in regions:
+        per = {}
+        for c in calls[a + 1:b]:
+            per.setdefault(c[2], []).append(c)
+        merged, pos = [], {k: 0 for k in per}
+        while any(pos[k] < len(per[k]) for k in per):
+            k = min((k for k in per if pos[k] < len(per[k])), key=lambda k: (pos[k] + 1) / len(per[k]))
+            merged.append(per[k][pos[k]])
+            pos[k] += 1
+        calls[a + 1:b] = merged
+    used_slots = sorted({e[1] for _, enc, _ in rec.calls for e in enc if e[0] == K_WEIGHT})
     remap = {s: i for i, s in enumerate(used_slots)}
-    names = sorted({n for n, _ in rec.calls})
+    names = sorted({n for n, _, _ in rec.calls if n not in ("fork", "join")})
+    nstreams = max(len(rec.streams), 1)
+    if nstreams > 3:
+        raise _lib.FFError(f"plan recording: {nstreams} streams seen, the executor replays at most 3")
     fid = {n: i for i, n in enumerate(names)}
 
     with open(stem + ".ffplan", "wb") as f:
@@ -217,9 +265,12 @@ def export_plan(model, lr: torch.Tensor, stem: str) -> dict:
             b = slots[s][0].encode()
             f.write(struct.pack("<I", len(b)) + b + struct.pack("<q", slots[s][2]))
         f.write(struct.pack("<q4i4i", wbytes, *lr.shape, *out.shape))
-        f.write(struct.pack("<I", len(rec.calls)))
-        for n, enc in rec.calls:
-            f.write(struct.pack("<HH", fid[n], len(enc)))
+        f.write(struct.pack("<I", len(calls)))
+        for n, enc, sidx in calls:
+            if n in ("fork", "join"):
+                f.write(struct.pack("<HHH", FID_MARK, 0, 0 if n == "fork" else 1))
+                continue
+            f.write(struct.pack("<HHH", fid[n], len(enc), sidx))
             for kind, a, b in enc:
                 if kind == K_FLT:
                     f.write(struct.pack("<Bxxxdq", kind, a, 0))
@@ -240,7 +291,7 @@ def export_plan(model, lr: torch.Tensor, stem: str) -> dict:
             b = path.encode()
             f.write(struct.pack("<I", len(b)) + b + struct.pack("<q", nbytes))
             f.write(raw.cpu().numpy().tobytes())
-    return {"calls": len(rec.calls), "entry_points": len(names), "slots": len(used_slots),
+    return {"calls": sum(1 for n, _, _ in rec.calls if n not in ("fork", "join")), "streams": nstreams, "entry_points": len(names), "slots": len(used_slots),
             "weight_bytes": sum(slots[s][2] for s in used_slots), "workspace_bytes": wbytes,
             "activation_bytes_unpacked": sum(w[0] for w in rec.work if w[1] >= 0), "in_shape": tuple(lr.shape), "out_shape": tuple(out.shape)}
 

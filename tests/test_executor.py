@@ -30,6 +30,22 @@ def test_workspace_packing_never_aliases_live_buffers():
     assert total < sum(w[0] for w in work)                        # reuse happened
 
 
+def test_workspace_packing_keeps_concurrent_streams_apart():
+    """Inside a fork..join region buffers of different streams never share bytes even when their tape intervals are disjoint
+    (the tape lists one stream's launches after the other's, the device runs them side by side)."""
+    from isr2_amd.plan import _pack_offsets
+    work = [[4096, 10, 20, {1}], [4096, 30, 40, {2}], [4096, 50, 60, {0}], [4096, 61, 70, {0}], [4096, 2, 3, {0}], [4096, 90, 95, {0}]]
+    offs, total = _pack_offsets(work, regions=[(5, 80)])
+    spans = [(o, o + 4096) for o in offs]
+    def disjoint(a, b):
+        return spans[a][1] <= spans[b][0] or spans[b][1] <= spans[a][0]
+    assert disjoint(0, 1) and disjoint(0, 2) and disjoint(1, 2) and disjoint(0, 3) and disjoint(1, 3)
+    assert offs[2] == offs[3]                                     # same stream, disjoint lifetimes: reuse
+    assert offs[4] == offs[5] == offs[0] or total <= 3 * 4096     # outside the region the plain lifetime rule applies
+    offs1, total1 = _pack_offsets([w[:3] for w in work])          # no stream sets, no regions: one slot serves all
+    assert total1 == 4096
+
+
 def test_create_rejects_bad_plans(tmp_path):
     from isr2_amd import lib
     L = lib.load()
@@ -38,12 +54,12 @@ def test_create_rejects_bad_plans(tmp_path):
     p = tmp_path / "garbage.ffplan"
     p.write_bytes(b"not a plan at all")
     assert L.ff_create(str(p).encode(), ctypes.byref(h)) != 0
-    assert b"FFPLAN2" in L.ff_last_error()
+    assert b"FFPLAN3" in L.ff_last_error()
     p = tmp_path / "abi.ffplan"
-    p.write_bytes(b"FFPLAN2\0" + struct.pack("<iI", 999, 0))
+    p.write_bytes(b"FFPLAN3\0" + struct.pack("<iI", 999, 0))
     assert L.ff_create(str(p).encode(), ctypes.byref(h)) != 0 and b"ABI" in L.ff_last_error()
     p = tmp_path / "name.ffplan"
-    p.write_bytes(b"FFPLAN2\0" + struct.pack("<iI", L.ff_abi_version(), 1) + struct.pack("<I", 9) + b"ff_nosuch")
+    p.write_bytes(b"FFPLAN3\0" + struct.pack("<iI", L.ff_abi_version(), 1) + struct.pack("<I", 9) + b"ff_nosuch")
     assert L.ff_create(str(p).encode(), ctypes.byref(h)) != 0 and b"ff_nosuch" in L.ff_last_error()
     assert L.ff_forward(None, None, 1, 1, 1, None, None) != 0     # null handle is an error, not a crash
     assert L.ff_destroy(None) == 0
@@ -68,6 +84,7 @@ def test_native_executor_replays_the_python_forward_bit_for_bit(tmp_path, synth_
     info = plan.export_plan(model, lr, stem)
     print("plan:", info)
     assert info["calls"] > 1000 and info["workspace_bytes"] < info["activation_bytes_unpacked"] / 4
+    assert info["streams"] == 3                                          # the host's three-stream schedule is part of the plan
     ref = model(lr)
     nat = plan.NativeModel(stem + ".ffplan", stem + ".ffwts")
     try:
@@ -90,6 +107,14 @@ def test_native_executor_replays_the_python_forward_bit_for_bit(tmp_path, synth_
             nat(torch.zeros(1, 3, 40, 48, device=dev))                   # a plan is for one input shape
     finally:
         nat.close()
+    # the same model as a single-stream plan: fewer workspace bytes, same result
+    info1 = plan.export_plan(model, lr, stem + "_1s", multi_stream=False)
+    assert info1["streams"] == 1 and info1["workspace_bytes"] <= info["workspace_bytes"]
+    nat1 = plan.NativeModel(stem + "_1s.ffplan", stem + "_1s.ffwts")
+    try:
+        assert torch.equal(nat1(lr), ref)
+    finally:
+        nat1.close()
     h = ctypes.c_void_p()
     L = plan._lib.load()
     assert L.ff_create((stem + ".ffplan").encode(), ctypes.byref(h)) == 0
