@@ -43,17 +43,21 @@ struct ConvBfParams {
   int vec_out;     // 16-byte epilogue: no shuffle, Cout % 4 == 0, 16-byte aligned out / res rows
 };
 
-#define ROWB 144   // bytes per LDS row: 64 hi + 64 lo + 16 pad
-#define BKB 32
-
-template <int BM, int BN, int WM, int WN, bool VEC4, int NTERMS>
+// BKB = k-values per chunk (one barrier per chunk).  32: the original form.  64 (r2): twice the MFMAs between barriers -- the
+// 8-wave 128-row tiles issue only 12 MFMAs per wave and chunk at 32, and the barrier + staging round trip per chunk, not the
+// MFMA pipe, set their time (SQ counters, tools/gemm_prof.py: MFMA pipe 28 % busy on the 1024 -> 2048 NAFNet GEMM).
+//   LDS row = [BKB hi | BKB lo | 16 B pad]: 144 B (36 dwords) or 272 B (68 dwords), both = 4 (mod 32) dwords: conflict-free b128 reads.
+template <int BM, int BN, int WM, int WN, bool VEC4, int NTERMS, int BKB>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16_kernel(ConvBfParams p) {
+  constexpr int ROWB = BKB * 4 + 16, PLB = BKB * 2;   // bytes per LDS row / per plane of a row
+  constexpr int KQ = BKB / 4, QB = BKB / 8;       // 4-float quads / 16-byte bf16 items per row and plane
   constexpr int NT = WM * WN * 64;                // threads
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
-  constexpr int RPP = NT / 8;                     // A rows staged per pass (8 k-quads per row)
+  constexpr int RPP = NT / KQ;                    // A rows staged per pass
   constexpr int AQ = BM / RPP;                    // A quads (4 k-values) staged per thread
-  constexpr int BI = (BN * 8 + NT - 1) / NT;      // B 16-byte items staged per thread (hi+lo planes)
+  constexpr int BI = (BN * 2 * QB + NT - 1) / NT; // B 16-byte items staged per thread (hi+lo planes)
+  static_assert(BM % RPP == 0, "A staging must tile the rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;                       // [2][BM][ROWB]
   unsigned char* Bs = smem + 2 * BM * ROWB;       // [2][BN][ROWB]
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16_kernel(ConvBfPar
   const int L = ff_xcd_remap(blockIdx.x, mtiles * ntiles);
   const int m0 = (L / ntiles) * BM, n0 = (L % ntiles) * BN;
 
-  const int srow = tid >> 3, kq = tid & 7;        // A staging: row srow + RPP*i, k-quad kq
+  const int srow = tid / KQ, kq = tid % KQ;       // A staging: row srow + RPP*i, k-quad kq
   int a_b[AQ], a_iy[AQ], a_ix[AQ];
   bool a_ok[AQ];
 #pragma unroll
@@ -140,10 +144,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16_kernel(ConvBfPar
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
       const int id = tid + NT * j;                 // [plane][row][q]
-      const int plane = id / (BN * 4), rem = id % (BN * 4);
-      const int r = rem >> 2, q = rem & 3;
+      const int plane = id / (BN * QB), rem = id % (BN * QB);
+      const int r = rem / QB, q = rem % QB;
       uint4 v = {0u, 0u, 0u, 0u};
-      if (id < BN * 8 && (NTERMS == 3 || plane == 0) && n0 + r < p.Cout) {
+      if (id < BN * 2 * QB && (NTERMS == 3 || plane == 0) && n0 + r < p.Cout) {
         const __bf16* src = (plane ? p.w_lo : p.w_hi) + (long long)(n0 + r) * p.Kp + k0 + 8 * q;
         v = *reinterpret_cast<const uint4*>(src);
       }
@@ -164,15 +168,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16_kernel(ConvBfPar
       }
       unsigned char* dst = As + (size_t)(buf * BM + srow + RPP * i) * ROWB + kq * 8;
       *reinterpret_cast<bf16x4*>(dst) = hi;
-      if (NTERMS >= 2) *reinterpret_cast<bf16x4*>(dst + 64) = lo;
+      if (NTERMS >= 2) *reinterpret_cast<bf16x4*>(dst + PLB) = lo;
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
       const int id = tid + NT * j;
-      const int plane = id / (BN * 4), rem = id % (BN * 4);
-      const int r = rem >> 2, q = rem & 3;
-      if (id < BN * 8 && (NTERMS == 3 || plane == 0))
-        *reinterpret_cast<uint4*>(Bs + (size_t)(buf * BN + r) * ROWB + plane * 64 + q * 16) = rb[j];
+      const int plane = id / (BN * QB), rem = id % (BN * QB);
+      const int r = rem / QB, q = rem % QB;
+      if (id < BN * 2 * QB && (NTERMS == 3 || plane == 0))
+        *reinterpret_cast<uint4*>(Bs + (size_t)(buf * BN + r) * ROWB + plane * PLB + q * 16) = rb[j];
     }
   };
 
@@ -193,19 +197,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16_kernel(ConvBfPar
     const int buf = c & 1;
     if (c + 1 < nchunks) load_chunk((c + 1) * BKB);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < BKB / 16; ++s) {
       bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const unsigned char* ap = As + (size_t)(buf * BM + wr * TM + i * 32 + l31) * ROWB + 32 * s + 16 * hh;
         ah[i] = *reinterpret_cast<const bf16x8*>(ap);
-        if (NTERMS >= 2) al[i] = *reinterpret_cast<const bf16x8*>(ap + 64);
+        if (NTERMS >= 2) al[i] = *reinterpret_cast<const bf16x8*>(ap + PLB);
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const unsigned char* bp = Bs + (size_t)(buf * BN + wc * TN + j * 32 + l31) * ROWB + 32 * s + 16 * hh;
         bh[j] = *reinterpret_cast<const bf16x8*>(bp);
-        if (NTERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(bp + 64);
+        if (NTERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(bp + PLB);
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -320,26 +324,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16_kernel(ConvBfPar
   FF_DISPATCH_ACT(p.act, epilogue)
 }
 
-template <int BM, int BN, int WM, int WN, int NT>
+template <int BM, int BN, int WM, int WN, int NT, int BKB = 32>
 static int launch_bf(const ConvBfParams& p, bool vec4, hipStream_t st) {
   const int mt = ff_cdiv(p.M, BM), nt = ff_cdiv(p.Cout, BN);
-  const size_t lds = (size_t)2 * (BM + BN) * ROWB;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * (BKB * 4 + 16);
+  static_assert(lds <= 160 * 1024 && lds >= (size_t)WM * WN * 32 * 36 * 4, "LDS budget (staging ring; the epilogue patch reuses it)");
   dim3 grid((unsigned)(mt * nt)), block(WM * WN * 64);
   if (lds > 64 * 1024) {
     static bool attr_set[2] = {false, false};
     if (!attr_set[vec4 ? 1 : 0]) {
-      hipError_t e = vec4 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16_kernel<BM, BN, WM, WN, true, NT>),
+      hipError_t e = vec4 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16_kernel<BM, BN, WM, WN, true, NT, BKB>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16_kernel<BM, BN, WM, WN, false, NT>),
+                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16_kernel<BM, BN, WM, WN, false, NT, BKB>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { ff_set_error("ff_conv2d_bf16s: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return FF_ERR_LAUNCH; }
       attr_set[vec4 ? 1 : 0] = true;
     }
   }
   if (vec4)
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, true, NT>), grid, block, lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, true, NT, BKB>), grid, block, lds, st, p);
   else
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, false, NT>), grid, block, lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, false, NT, BKB>), grid, block, lds, st, p);
   FF_LAUNCH_CHECK("ff_conv2d_bf16s");
   return FF_OK;
 }
@@ -354,6 +359,9 @@ static int dispatch_bf(const ConvBfParams& p, bool vec4, int cfg, hipStream_t st
     case 5: return launch_bf<128, 128, 2, 4, NT>(p, vec4, st);      // 8 waves (two per SIMD), 64x32 per wave
     case 6: return launch_bf<256, 128, 4, 2, NT>(p, vec4, st);      // 8 waves, 64x64 per wave
     case 7: return launch_bf<128, 64, 4, 2, NT>(p, vec4, st);       // 8 waves, 32x32 per wave
+    // 64-deep chunks (Kp and the per-tap Cp must be multiples of 64; checked by the caller below)
+    case 8: return launch_bf<128, 128, 2, 4, NT, 64>(p, vec4, st);
+    case 9: return launch_bf<128, 64, 4, 2, NT, 64>(p, vec4, st);
     default: ff_set_error("ff_conv2d_bf16s: bad tile_hint %d", cfg); return FF_ERR_ARG;
   }
 }
@@ -401,6 +409,8 @@ extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_
     else if (Cout > 256 || (Cout > 128 && p.K >= 512)) cfg = 5;
     else cfg = 7;
   }
+  const bool k64 = Kp % 64 == 0 && (Cp == 0 || Cp % 64 == 0) && vec4;
+  if (cfg >= 8 && !k64) cfg = cfg == 8 ? 5 : 7;
   switch (nterms) {
     case 1: return dispatch_bf<1>(p, vec4, cfg, st);
     case 2: return dispatch_bf<2>(p, vec4, cfg, st);

@@ -149,6 +149,34 @@ def test_linear_matches_torch(dev, gemm_mode):
     close(ops.linear(x, w.clone(), b, dynamic_w=True), F.linear(x, w, b), GEMM_TOL[gemm_mode], "linear dynamic weight")
 
 
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("M,K,N,k", [(4096, 1024, 2048, 1), (1111, 192, 200, 1), (900, 180, 96, 1), (30 * 30, 64, 130, 3), (24 * 24, 128, 64, 2)])
+def test_gemm_tile_forms_agree_with_torch(dev, hint, M, K, N, k):
+    """Every tile form of the bf16x3 implicit GEMM (4- and 8-wave tiles, 32- and 64-deep chunks; hints 8 / 9 fall back to the 32-deep
+    form when K does not pad to 64) on ragged and exact shapes, 1x1 / 3x3 / 2x2-stride-2, with residual and per-channel scale."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_conv
+    prev = ops.gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    ops.set_halo(False)
+    try:
+        hw = int(round(math.sqrt(M))) if k > 1 else None
+        B, H, W = (1, hw, hw) if k > 1 else (1, 1, M)
+        x = rnd(B, K, H, W, dev=dev, seed=120, scale=1.0)
+        w = rnd(N, K, k, k, dev=dev, seed=121, scale=1.0 / math.sqrt(K * k * k))
+        b = rnd(N, dev=dev, seed=122, scale=0.1)
+        mul = rnd(N, dev=dev, seed=123)
+        st, pd = (2, 0) if k == 2 else (1, k // 2)
+        ref = F.conv2d(x, w, b, stride=st, padding=pd)
+        res = rnd(*ref.permute(0, 2, 3, 1).shape, dev=dev, seed=124)
+        out = ops.conv2d(x.permute(0, 2, 3, 1).contiguous(), pack_conv(w), b, ksize=(k, k), stride=(st, st), pad=(pd, pd), res=res, mul=mul,
+                         tile_hint=hint)
+        close(out, res + (mul.view(1, -1, 1, 1) * ref).permute(0, 2, 3, 1), GEMM_TOL["bf16x3"], f"tile form {hint}")
+    finally:
+        ops.set_halo(True)
+        ops.set_gemm_mode(prev)
+
+
 @pytest.mark.parametrize("M", [65536, 1000, 77])
 def test_token_mlp_fused(dev, M):
     """LN + fc1 + GELU + fc2 + residual in one launch (bf16x3) against the PyTorch fp32 chain."""

@@ -26,5 +26,5 @@ recs = prof.records()
 tot = sum(r[1] for r in recs)
 print(f"{which}: {len(recs)} launches, {tot:.2f} ms")
 lo, hi = (8, 8 + 40) if which != "naf" else (0, 60)
-for i, (name, ms, fl, by) in enumerate(recs[:120]):
+for i, (name, ms, fl, by) in enumerate(recs[:int(os.environ.get("FF_TL_N", "120"))]):
     print(f"{i:4d} {name:18s} {ms * 1e3:8.1f} us  {fl / max(ms, 1e-9) / 1e9:7.1f} TF  {by / max(ms, 1e-9) / 1e6:7.0f} GB/s")
