@@ -1,7 +1,7 @@
 // Small fused kernels of the fusion stack and the DAT channel attention statistics.
 //   ff_chan_gram / ff_chan_attn_weights  dat_arch.py:627-647  (L2-normalised q,k over ALL tokens, 30x30 gram
 //                                        per head, softmax) -> block-diagonal 180x180 matrix fed to ff_conv2d
-//   ff_band_mha_core                     large_kernel_attention.py:222-224 (9-token, 4-head attention per pixel)
+//   ff_band_mha_core                     large_kernel_attention.py:222-224 (9-token, 4-head attention per pixel) and :393 (3 experts, 8 heads)
 //   ff_band_weight                       multi_domain_frequency.py:498-503
 //   ff_freq_guidance                     enhanced_fusion.py:533-542
 //   ff_dynamic_gates                     fusion_network.py:226-234
@@ -186,10 +186,11 @@ __global__ __launch_bounds__(256) void band_mha_core_kernel(const float* __restr
 
 extern "C" int ff_band_mha_core(const float* qkv, float* out, long long P, int nbands, int heads, void* stream) {
   FF_CHECK_ARG(qkv && out && P > 0 && heads > 0, "ff_band_mha_core: bad args");
-  FF_CHECK_ARG(nbands == 9, "ff_band_mha_core: built for the 9-band decomposition (got %d)", nbands);
+  FF_CHECK_ARG(nbands == 9 || nbands == 3, "ff_band_mha_core: built for 9 tokens (frequency bands) or 3 (experts), got %d", nbands);
   long long nb = (P * nbands * heads + 255) / 256;
   if (nb > 16384) nb = 16384;
-  hipLaunchKernelGGL(band_mha_core_kernel<9>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, qkv, out, P, heads);
+  if (nbands == 9) hipLaunchKernelGGL(band_mha_core_kernel<9>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, qkv, out, P, heads);
+  else hipLaunchKernelGGL(band_mha_core_kernel<3>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, qkv, out, P, heads);
   FF_LAUNCH_CHECK("ff_band_mha_core");
   return FF_OK;
 }

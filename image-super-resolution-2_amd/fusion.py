@@ -12,6 +12,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+from . import lib as _lib
 from . import ops
 from .prep import pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv
 
@@ -167,6 +168,78 @@ class CrossBandLKA:
         for i in range(nb):
             ops.linear(ximg[..., E * i:E * (i + 1)], *self.outp, res=bands[..., 3 * i:3 * i + 3], out=out[..., 3 * i:3 * i + 3])
         return out
+
+
+class Collaborative:
+    """EnhancedCollaborativeWithLKA in eval mode (large_kernel_attention.py:250-419), live only in the cached-mode forward
+    (enhanced_fusion.py:756-812): expert features [1,C,h,w] -> one gain per expert and colour channel.  Same building blocks as
+    CrossBandLKA with 3 tokens of 128 channels per pixel; the three experts are batched as 3*128 depth-wise channels / 3P rows."""
+
+    def __init__(self, sd: SD, dev, p: str = "collaborative", heads: int = 8):
+        self.heads, self.dev, E = heads, dev, 128
+        self.align = [_lin1x1(sd, f"{p}.align_layers.{n}", dev) for n in ("hat", "dat", "nafnet")]
+        self.norm1 = (sd[p + ".norm1.weight"].to(dev), sd[p + ".norm1.bias"].to(dev))
+        self.norm2 = (sd[p + ".norm2.weight"].to(dev), sd[p + ".norm2.bias"].to(dev))
+        self.in_proj = (sd[p + ".cross_attn.in_proj_weight"].to(dev).contiguous(), sd[p + ".cross_attn.in_proj_bias"].to(dev))
+        self.out_proj = (sd[p + ".cross_attn.out_proj.weight"].to(dev).contiguous(), sd[p + ".cross_attn.out_proj.bias"].to(dev))
+        self.ffn0 = (sd[p + ".ffn.0.weight"].to(dev).contiguous(), sd[p + ".ffn.0.bias"].to(dev))
+        self.ffn2 = (sd[p + ".ffn.2.weight"].to(dev).contiguous(), sd[p + ".ffn.2.bias"].to(dev))
+        q = p + ".lka_global"
+        sdd = {k: v.to(dev) for k, v in sd.items() if k.startswith(q)}
+        s1, t1 = bn_scale_shift(sdd, q + ".norm1")
+        s2, t2 = bn_scale_shift(sdd, q + ".norm2")
+        self.bn1 = (s1.repeat(3).contiguous(), t1.repeat(3).contiguous())
+        self.dw5 = pack_dw(sdd[q + ".lka.local_conv.weight"]).repeat(1, 3).contiguous()
+        self.dwh = pack_dw(sdd[q + ".lka.h_conv.weight"]).repeat(1, 3).contiguous()
+        self.dwv = pack_dw(sdd[q + ".lka.v_conv.weight"]).repeat(1, 3).contiguous()
+        sb, tb = bn_scale_shift(sdd, q + ".lka.bn")
+        self.pw = fold_bn_after_conv(sdd[q + ".lka.pw_conv.weight"].reshape(E, E), None, sb, tb)
+        self.scale1, self.scale2 = float(sdd[q + ".scale1"].cpu()), float(sdd[q + ".scale2"].cpu())
+        w0, b0 = _lin1x1(sd, q + ".ffn.0", dev)
+        self.lffn0 = ((w0 * s2[None, :]).contiguous(), (b0 + w0 @ t2).contiguous())      # eval BatchNorm folded into ffn.0
+        self.lffn2 = _lin1x1(sd, q + ".ffn.2", dev)
+        self.mod0 = [_lin1x1(sd, f"{p}.modulation.{i}.0", dev) for i in range(3)]
+        self.mod3 = [_lin1x1(sd, f"{p}.modulation.{i}.3", dev) for i in range(3)]
+        self.g_scale = torch.full((3,), 0.2, device=dev)
+        self.g_shift = torch.full((3,), 0.9, device=dev)                                   # 1 + 0.2 (m - 0.5) = 0.9 + 0.2 m
+
+    def __call__(self, feats: Dict[str, T], hr_hw, taps: Optional[dict] = None):
+        """feats: NCHW {hat [1,180,h,w], dat [1,180,h,w], nafnet [1,64,h,w]} -> three device vectors [3] of per-channel gains."""
+        E, ne = 128, 3
+        shapes = {tuple(feats[k].shape[2:]) for k in ("hat", "dat", "nafnet")}
+        if len(shapes) != 1:
+            raise _lib.FFError(f"collaborative: the cached features must share one resolution (cache.py writes them at LR size), got {shapes}")
+        h, w = next(iter(shapes))
+        P = h * w
+        tok = torch.empty((1, h, w, ne * E), device=self.dev, dtype=torch.float32)
+        for i, k in enumerate(("hat", "dat", "nafnet")):
+            ops.linear(ops.nchw_to_nhwc(feats[k].to(self.dev, torch.float32)), *self.align[i], out=tok[..., E * i:E * (i + 1)])
+        rows = tok.reshape(P * ne, E)
+        qkv = ops.linear(ops.layernorm(rows, *self.norm1), *self.in_proj)
+        att = ops.band_mha_core(qkv, P, ne, self.heads)
+        x = ops.linear(att, *self.out_proj, res=rows)
+        f = ops.linear(ops.layernorm(x, *self.norm2), *self.ffn0, act="gelu")
+        x = ops.linear(f, *self.ffn2, res=x)
+        # LKA block, the three experts at once
+        ximg = x.reshape(1, h, w, ne * E)
+        t = ops.affine(ximg, *self.bn1)
+        a = ops.dwconv2d(t, self.dw5, None, ksize=(5, 5), pad=(2, 2))
+        a = ops.dwconv2d(a, self.dwh, None, ksize=(1, 21), pad=(0, 10))
+        a = ops.dwconv2d(a, self.dwv, None, ksize=(21, 1), pad=(10, 0))
+        a = ops.linear(a.reshape(P * ne, E), *self.pw, act="sigmoid")
+        x = ops.fma3(x, t.reshape(P * ne, E), a, self.scale1)
+        f = ops.linear(x, *self.lffn0, act="gelu")
+        x = ops.linear(f, *self.lffn2, res=x, alpha=self.scale2)
+        ximg = x.reshape(1, h, w, ne * E)
+        gains = []
+        for i in range(ne):
+            up = ops.resize(ximg[..., E * i:E * (i + 1)], hr_hw)                          # [1,H,W,128] bilinear
+            m = ops.pool_mean(ops.linear(up, *self.mod0[i], act="gelu"))                   # [1,32]
+            m = ops.vec_mlp(m, self.mod3[i][0], self.mod3[i][1], "sigmoid")                # [1,3]
+            if taps is not None:
+                taps[f"collab.mod{i}"] = m
+            gains.append(ops.affine(m, self.g_scale, self.g_shift).reshape(3))
+        return gains
 
 
 class BandFusion:
@@ -374,6 +447,8 @@ class FusionHIP:
         self.refine = [_conv_b(sd, f"refine_net.{i}", dev) for i in (0, 2, 4, 6)]
         self.res_scale = float(sd["residual_scale"].cpu())
         self.edge = EdgeRefine(sd, dev)
+        # the cached-mode forward's collaborative block, when the checkpoint carries it (synthetic weights: parts += "collab")
+        self.collab = Collaborative(sd, dev) if "collaborative.norm1.weight" in sd else None
 
     def pre(self, lr: T) -> dict:
         """Everything that depends on the LR input only (frequency bands, cross-band attention, band fusion -> guidance,
@@ -389,8 +464,9 @@ class FusionHIP:
         return dict(raw=raw, xb=xb, b3=b3, guide=guide, lr_nhwc=lr_nhwc, gates=gates, dif=dif, up=up)
 
     def forward(self, lr: T, experts: Dict[str, T], taps: Optional[dict] = None, pre: Optional[dict] = None,
-                out: Optional[T] = None) -> T:
-        """lr NCHW [1,3,h,w]; experts: dict of NCHW [1,3,4h,4w] -> SR NCHW [1,3,4h,4w]."""
+                out: Optional[T] = None, feats: Optional[Dict[str, T]] = None) -> T:
+        """lr NCHW [1,3,h,w]; experts: dict of NCHW [1,3,4h,4w] -> SR NCHW [1,3,4h,4w].  feats (cached-mode forward only,
+        enhanced_fusion.py:794): the hooked expert features; every expert output is then scaled by its collaborative gain."""
         _, _, h, w = lr.shape
         dev = lr.device
         if pre is None:
@@ -399,6 +475,14 @@ class FusionHIP:
         e9 = torch.empty((1, 4 * h, 4 * w, 9), device=dev, dtype=torch.float32)
         for i, k in enumerate(("hat", "dat", "nafnet")):
             ops.nchw_to_nhwc(experts[k], out=e9[..., 3 * i:3 * i + 3])
+        if feats is not None:
+            if self.collab is None:
+                raise _lib.FFError("expert features were passed but the checkpoint holds no collaborative.* weights")
+            gains = self.collab(feats, (4 * h, 4 * w), taps)
+            for i, k in enumerate(("hat", "dat", "nafnet")):
+                ops.mix2(e9[..., 3 * i:3 * i + 3], ca=gains[i], clamp01=True, out=e9[..., 3 * i:3 * i + 3])       # :415-416
+                if taps is not None:
+                    taps[f"collab.out.{k}"] = e9[..., 3 * i:3 * i + 3]
         hier = self.hier(e9)
         fused = ops.fuse_blend(e9, hier, guide, gates, dif)
         if taps is not None:

@@ -94,6 +94,29 @@ class FreqFusionHIP:
         return outs, feats
 
     @torch.no_grad()
+    def forward_with_precomputed(self, lr: T, expert_outputs, expert_features=None, taps: Optional[dict] = None) -> T:
+        """CompleteEnhancedFusionSR.forward_with_precomputed (enhanced_fusion.py:756-812): the cached-mode forward.  The expert
+        outputs {hat,dat,nafnet: [1,3,4h,4w]} and, optionally, their hooked features (isr2_amd/cache.py files, or
+        experts_with_features()) come from the caller; only the fusion stack runs, with the collaborative block live when
+        features are given.  The forward half of SURVEY 8f rank 1; no backward is built."""
+        if lr.dim() != 4 or lr.shape[0] != 1 or lr.shape[1] != 3:
+            raise _lib.FFError(f"expected lr of shape [1,3,h,w], got {tuple(lr.shape)}")
+        lr = lr.to(self.dev, torch.float32).contiguous()
+        _, _, h, w = lr.shape
+        ex = {}
+        for k in ("hat", "dat", "nafnet"):
+            t = expert_outputs[k]
+            t = t.unsqueeze(0) if t.dim() == 3 else t
+            if tuple(t.shape) != (1, 3, 4 * h, 4 * w):
+                raise _lib.FFError(f"expert output {k}: expected [1,3,{4 * h},{4 * w}], got {tuple(t.shape)}")
+            ex[k] = t.to(self.dev, torch.float32).contiguous()
+        feats = None
+        if expert_features is not None:
+            feats = {k: (v.unsqueeze(0) if v.dim() == 3 else v).to(self.dev, torch.float32).contiguous() for k, v in expert_features.items()}
+        with torch.cuda.device(self.dev):
+            return self.fusion.forward(lr, ex, taps, feats=feats)
+
+    @torch.no_grad()
     def forward(self, lr: T, taps: Optional[dict] = None, out: Optional[T] = None) -> T:
         if lr.dim() != 4 or lr.shape[0] < 1 or lr.shape[1] != 3:
             raise _lib.FFError(f"expected lr of shape [B,3,h,w], got {tuple(lr.shape)}")

@@ -291,6 +291,58 @@ def _fusion_spec() -> List[Spec]:
     return s
 
 
+def _collab_spec() -> List[Spec]:
+    """EnhancedCollaborativeWithLKA (large_kernel_attention.py:250-330): read only by the cached-mode forward
+    (`forward_with_precomputed`, enhanced_fusion.py:756-812) -- the eval forward never passes expert features, so the default
+    `parts` of param_spec()/synth_state_dict() leave these keys out (tests/test_weights_spec.py lists them as dead at inference)."""
+    s: List[Spec] = []
+    c = "collaborative."
+
+    def conv(n, o, i, k=1, bias=True, kh=None, kw=None, groups=1):
+        kh = k if kh is None else kh
+        kw = k if kw is None else kw
+        s.append((f"{c}{n}.weight", (o, i // groups, kh, kw), ("w", 1.0)))
+        if bias:
+            s.append((f"{c}{n}.bias", (o,), ("b",)))
+
+    def bn(n, ch):
+        s.append((f"{c}{n}.weight", (ch,), ("g",)))
+        s.append((f"{c}{n}.bias", (ch,), ("beta",)))
+        s.append((f"{c}{n}.running_mean", (ch,), ("rm",)))
+        s.append((f"{c}{n}.running_var", (ch,), ("rv",)))
+
+    D = 128
+    conv("align_layers.hat", D, EMBED)
+    conv("align_layers.dat", D, EMBED)
+    conv("align_layers.nafnet", D, 64)
+    s.append((c + "cross_attn.in_proj_weight", (3 * D, D), ("w", 1.0)))
+    s.append((c + "cross_attn.in_proj_bias", (3 * D,), ("b",)))
+    s.append((c + "cross_attn.out_proj.weight", (D, D), ("w", 1.0)))
+    s.append((c + "cross_attn.out_proj.bias", (D,), ("b",)))
+    for n in ("norm1", "norm2"):
+        s.append((f"{c}{n}.weight", (D,), ("g",)))
+        s.append((f"{c}{n}.bias", (D,), ("beta",)))
+    s.append((c + "ffn.0.weight", (2 * D, D), ("w", 1.0)))
+    s.append((c + "ffn.0.bias", (2 * D,), ("b",)))
+    s.append((c + "ffn.2.weight", (D, 2 * D), ("w", 1.0)))
+    s.append((c + "ffn.2.bias", (D,), ("b",)))
+    s.append((c + "lka_global.scale1", (), ("sc", 0.1, 0.2)))
+    s.append((c + "lka_global.scale2", (), ("sc", 0.1, 0.2)))
+    bn("lka_global.norm1", D)
+    conv("lka_global.lka.local_conv", D, D, 5, bias=False, groups=D)
+    conv("lka_global.lka.h_conv", D, D, bias=False, kh=1, kw=21, groups=D)
+    conv("lka_global.lka.v_conv", D, D, bias=False, kh=21, kw=1, groups=D)
+    conv("lka_global.lka.pw_conv", D, D, 1, bias=False)
+    bn("lka_global.lka.bn", D)
+    bn("lka_global.norm2", D)
+    conv("lka_global.ffn.0", 2 * D, D)
+    conv("lka_global.ffn.2", D, 2 * D)
+    for i in range(3):
+        conv(f"modulation.{i}.0", D // 4, D)
+        conv(f"modulation.{i}.3", 3, D // 4)
+    return s
+
+
 HAT_PREFIX = "expert_ensemble.hat."
 DAT_PREFIX = "expert_ensemble.dat."
 NAF_PREFIX = "expert_ensemble.nafnet.nafnet."
@@ -306,6 +358,8 @@ def param_spec(parts=("hat", "dat", "nafnet", "fusion")) -> List[Spec]:
         out += _nafnet_spec(NAF_PREFIX)
     if "fusion" in parts:
         out += _fusion_spec()
+    if "collab" in parts:
+        out += _collab_spec()
     return out
 
 

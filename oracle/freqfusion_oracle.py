@@ -676,6 +676,52 @@ def fusion_forward(sd: SD, lr: T, experts: Dict[str, T], taps: Optional[dict] = 
     return refine_output(sd, fused, lr, taps)
 
 
+def collaborative(sd: SD, feats: Dict[str, T], outs: List[T], p: str = "collaborative", heads: int = 8, taps: Optional[dict] = None) -> List[T]:
+    """EnhancedCollaborativeWithLKA.forward in eval mode (large_kernel_attention.py:332-419): align the cached expert features to
+    128 channels, attend across the three experts at every pixel, LKA-refine each, and turn a pooled HR map into one gain per
+    expert and colour channel:  out_i * (1 + 0.2 (mod_i - 0.5)), clamped to [0, 1]."""
+    names = ["hat", "dat", "nafnet"]
+    al = [_conv(feats[n], sd, f"{p}.align_layers.{n}") for n in names]                     # :343-361 (channel counts match here)
+    h, w = min(a.shape[2] for a in al), min(a.shape[3] for a in al)
+    al = [a if a.shape[2:] == (h, w) else _bilinear(a, (h, w)) for a in al]                # :368-376
+    b, dim = al[0].shape[0], al[0].shape[1]
+    tok = torch.stack(al, dim=1).permute(0, 3, 4, 1, 2).reshape(b * h * w, len(names), dim)   # :382-391
+    tn = _ln(tok, sd, p + ".norm1")
+    qkv = F.linear(tn, sd[p + ".cross_attn.in_proj_weight"], sd[p + ".cross_attn.in_proj_bias"])
+    d = dim // heads
+    q, k, v = [t.reshape(-1, len(names), heads, d).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+    a = torch.softmax((q * d ** -0.5) @ k.transpose(-2, -1), dim=-1) @ v                   # nn.MultiheadAttention, dropout off in eval
+    a = a.transpose(1, 2).reshape(-1, len(names), dim)
+    tok = tok + F.linear(a, sd[p + ".cross_attn.out_proj.weight"], sd[p + ".cross_attn.out_proj.bias"])      # :393-395
+    tok = tok + _lin(F.gelu(_lin(_ln(tok, sd, p + ".norm2"), sd, p + ".ffn.0")), sd, p + ".ffn.2")           # :396
+    enh = tok.reshape(b, h, w, len(names), dim).permute(0, 3, 4, 1, 2)                     # :399-400
+    hs, ws_ = outs[0].shape[2], outs[0].shape[3]
+    res = []
+    for i, o in enumerate(outs):                                                           # :406-417
+        f = lka_block(sd, enh[:, i], p + ".lka_global")
+        fh = _bilinear(f, (hs, ws_))
+        m = F.gelu(_conv(fh, sd, f"{p}.modulation.{i}.0")).mean(dim=(2, 3), keepdim=True)
+        m = torch.sigmoid(_conv(m, sd, f"{p}.modulation.{i}.3"))
+        if taps is not None:
+            taps[f"collab.mod{i}"] = m.reshape(b, 3)
+            taps[f"collab.feat{i}"] = f
+        res.append((o * (1.0 + 0.2 * (m - 0.5))).clamp(0, 1))
+    return res
+
+
+@torch.no_grad()
+def forward_with_precomputed(sd: SD, lr: T, outs: Dict[str, T], feats: Optional[Dict[str, T]], taps: Optional[dict] = None) -> T:
+    """CompleteEnhancedFusionSR.forward_with_precomputed (enhanced_fusion.py:756-812): the cached-mode forward -- expert outputs
+    and features come from disk (f2: src/data/cached_dataset.py), only the fusion stack runs."""
+    ex = dict(outs)
+    if feats is not None:                                                                  # apply_collaborative_learning :466-496
+        enh = collaborative(sd, feats, [outs["hat"], outs["dat"], outs["nafnet"]], taps=taps)
+        ex = {"hat": enh[0], "dat": enh[1], "nafnet": enh[2]}
+        if taps is not None:
+            taps.update({f"collab.out.{k}": v for k, v in ex.items()})
+    return fusion_forward(sd, lr, ex, taps)
+
+
 @torch.no_grad()
 def forward(sd: SD, lr: T, taps: Optional[dict] = None) -> T:
     """CompleteEnhancedFusionSR.forward in eval mode (enhanced_fusion.py:694-754)."""

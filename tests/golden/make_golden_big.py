@@ -5,6 +5,8 @@
                                                        #   on one 510x339 1/f image (6 tiles), ~15-20 min
     python tests/golden/make_golden_big.py b2          # a B=2 48x48 batch through the reference (batched-forward parity)
     python tests/golden/make_golden_big.py hooks48     # the cached-expert features of forward_all_with_hooks
+    python tests/golden/make_golden_big.py precomp48   # the cached-mode forward (forward_with_precomputed, SURVEY 8f rank 1's forward
+                                                       #   half) on those features + expert outputs, collaborative block live
 
 A 1024x1024x3 fp32 output is 12.6 MB, so only data a test can check cheaply is stored:
   * for every tap (same names as make_golden.py): 4096 seeded samples + (mean, mean|x|, L2) over the whole tensor,
@@ -136,6 +138,43 @@ def hooks48(model, sd):
     return {k: list(v.shape) for k, v in feats.items()}
 
 
+def precomp48(model, sd):
+    """CompleteEnhancedFusionSR.forward_with_precomputed (enhanced_fusion.py:756-812) in eval mode on the 48x48 uint8 case: the
+    expert outputs and hooked features are the ones c48_u8.npz / hooks48.npz hold (checked here); the collaborative block
+    (large_kernel_attention.py:250-419), dead in the plain eval forward, gets the seeded `collab` weights."""
+    from isr2_amd.weights import synth_state_dict
+    from make_golden import SEED
+    sdc = synth_state_dict(SEED, parts=("hat", "dat", "nafnet", "fusion", "collab"))
+    res = model.load_state_dict(sdc, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys[:5]
+    model.eval()
+    lr = make_input("u8", 48, 48, 0)
+    ens = model.expert_ensemble
+    with contextlib.redirect_stdout(_io.StringIO()), torch.no_grad():
+        outputs, feats = ens.forward_all_with_hooks(lr)
+        final, inter = model.forward_with_precomputed(lr, outputs, feats, return_intermediates=True)
+    g = np.load(os.path.join(HERE, "c48_u8.npz"))
+    hk = np.load(os.path.join(HERE, "hooks48.npz"))
+    for k in ("hat", "dat", "nafnet"):
+        assert np.abs(outputs[k].numpy() - g[f"full/expert.{k}"]).max() < 1e-6, k       # same inputs as the committed fixtures
+        assert np.abs(feats[k].numpy() - hk[f"feat/{k}"]).max() < 1e-6, k
+    blob = {"final": final.numpy().astype(np.float32)}
+    for k, v in inter["enhanced_outputs"].items():
+        blob["enhanced/" + k] = v.numpy().astype(np.float32)
+    # pin the oracle's restatement of the same call
+    otaps = {}
+    oout = O.forward_with_precomputed(sdc, lr, {k: v for k, v in outputs.items()}, {k: v for k, v in feats.items()}, otaps)
+    for i in range(3):
+        blob[f"mod{i}"] = otaps[f"collab.mod{i}"].numpy().astype(np.float32)
+    rep = {"oracle_vs_reference_final_max_abs": float((oout - final).abs().max()),
+           "oracle_vs_reference_enhanced_max_abs": {k: float((otaps[f"collab.out.{k}"] - inter["enhanced_outputs"][k]).abs().max()) for k in ("hat", "dat", "nafnet")},
+           "gain_range": [float(min(blob[f"mod{i}"].min() for i in range(3))), float(max(blob[f"mod{i}"].max() for i in range(3)))],
+           "plain_vs_collab_final_max_abs": float((final - torch.from_numpy(g["full/final"])).abs().max())}
+    np.savez_compressed(os.path.join(HERE, "precomp48.npz"), **blob)
+    print("precomp48:", rep, flush=True)
+    return rep
+
+
 def main():
     what = sys.argv[1:] or ["tile256"]
     torch.manual_seed(0)
@@ -145,7 +184,7 @@ def main():
     rp = os.path.join(HERE, "big_pinning_report.json")
     report = json.load(open(rp)) if os.path.exists(rp) else {}
     for wname in what:
-        report[wname] = {"tile256": tile256, "config3": config3, "b2": b2, "hooks48": hooks48}[wname](model, sd)
+        report[wname] = {"tile256": tile256, "config3": config3, "b2": b2, "hooks48": hooks48, "precomp48": precomp48}[wname](model, sd)
         json.dump(report, open(rp, "w"), indent=1)
 
 
