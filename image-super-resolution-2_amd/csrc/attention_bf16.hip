@@ -17,7 +17,8 @@ struct AttnBfParams {
   float* out;
   const float* biasT;
   const float* rel;      // optional compact relative-position table [heads][(2wh-1)*(2ww-1)] (NULL: use biasT)
-  int rel_w, rel_n, lkw;  // 2ww-1, table entries per head, log2(kw)
+  int rel_w, rel_n, lkw;  // ww+kw-1, table entries per head, log2(kw)
+  int rel_gen, rel_base;  // overlapping keys (kh != wh): per-key offset table in LDS + rotated table (see the launcher)
   int ldq, ldo;
   int q_off, k_off, v_off, o_off;
   int B, H, W, Hp, Wp;
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
   int* ktok = reinterpret_cast<int*>(Vl + 32 * VROWB);   // [nchunks*AKC] token index of every key (or -1: zero key)
   int* kregAll = ktok + p.nkpad;                         // [nchunks*AKC] shift-region id of every key
   float* Tl = reinterpret_cast<float*>(kregAll + p.nkpad);   // [rel_n] this head's relative-position table (rel path)
+  int* kofs = reinterpret_cast<int*>(Tl + (p.rel ? p.rel_n : 0));   // [nkpad] ky * rel_w + kx of every key (rel_gen path)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
     }
     ktok[kidx] = tk;
     kregAll[kidx] = rid;
+    if (p.rel_gen) kofs[kidx] = kidx < nk ? (kidx / p.kw) * p.rel_w + kidx % p.kw : 0;
   }
   if (p.rel)
     for (int i = tid; i < p.rel_n; i += 512) Tl[i] = p.rel[(long long)head * p.rel_n + i];
@@ -157,7 +160,23 @@ __global__ __launch_bounds__(512) void window_attn_bf16_kernel(AttnBfParams p) {
       // biasQ is quad-interleaved [heads][nk/4][256 queries][4 keys]: accumulator registers 4g..4g+3 of a lane are four
       // consecutive keys of its query, i.e. ONE 16-byte load (16 loads per chunk and lane instead of 64; a half-wave
       // reads 512 contiguous bytes).
-      if (p.rel) {
+      if (p.rel_gen) {
+        // Overlapping key window (HAT OCAB, hat_arch.py:385-437: 16x16 queries, 24x24 keys): bias[q][k] = T[((ky - qy + a) * rel_w +
+        // (kx - qx + a)) mod rel_n] with a = wh - kh + 1 < 0 -- the reference indexes its table with negative numbers and PyTorch
+        // wraps them -- served from the ROTATED table U[i] = T[(i - m) mod rel_n] (prep.pack_rel_overlap), i = kofs[key] + lane part,
+        // where kofs = ky * rel_w + kx sits in LDS (kw is not a power of two) and four consecutive keys are one 16-byte read.
+        const int lane_base = p.rel_base - (qi / p.ww) * p.rel_w - (qi % p.ww);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int4 ko = *reinterpret_cast<const int4*>(kofs + c * AKC + t * 32 + 8 * g + 4 * hh);
+            st[t][4 * g + 0] = Tl[lane_base + ko.x];
+            st[t][4 * g + 1] = Tl[lane_base + ko.y];
+            st[t][4 * g + 2] = Tl[lane_base + ko.z];
+            st[t][4 * g + 3] = Tl[lane_base + ko.w];
+          }
+      } else if (p.rel) {
         // Relative-position bias gathered from the head's (2wh-1) x (2ww-1) table in LDS (3.8 KB) instead of streaming the
         // expanded [keys][queries] table (256 KB per head and window, 400 MB per launch from L2 / Infinity Cache):
         //   bias[q][k] = T[(qy - ky + wh - 1) * (2ww - 1) + (qx - kx + ww - 1)]        (hat_arch.py:882-899, dat_arch.py:300-318)
@@ -320,7 +339,9 @@ extern "C" int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_
   FF_CHECK_ARG(qkv && out && (biasT || rel_table), "ff_window_attn_bf16s: null pointer");
   FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_window_attn_bf16s: nterms must be 1 or 3");
   FF_CHECK_ARG(rel_table || ((kh * kw) % 4 == 0 && (((uintptr_t)biasT) & 15) == 0), "ff_window_attn_bf16s: the quad-interleaved bias table needs kh*kw %% 4 == 0 and 16-byte alignment");
-  FF_CHECK_ARG(!rel_table || (kh == wh && kw == ww && (kw & (kw - 1)) == 0 && kw >= 8), "ff_window_attn_bf16s: the relative-position table needs keys == query window and a power-of-two window width >= 8");
+  const bool rel_gen = rel_table && (kh != wh || kw != ww);
+  FF_CHECK_ARG(!rel_table || rel_gen || ((kw & (kw - 1)) == 0 && kw >= 8), "ff_window_attn_bf16s: the relative-position table needs a power-of-two window width >= 8 when keys == query window");
+  FF_CHECK_ARG(!rel_gen || (kw % 8 == 0 && shift_h == 0 && shift_w == 0), "ff_window_attn_bf16s: the overlapping-window table needs kw %% 8 == 0 and no shift");
   FF_CHECK_ARG(wh * ww == 256, "ff_window_attn_bf16s: query window must hold 256 tokens (got %dx%d)", wh, ww);
   FF_CHECK_ARG(d > 0 && d <= 32 && heads > 0, "ff_window_attn_bf16s: head dim %d unsupported (<=32)", d);
   FF_CHECK_ARG(kh >= wh && kw >= ww && (kh - wh) % 2 == 0 && (kw - ww) % 2 == 0, "ff_window_attn_bf16s: bad key window");
@@ -330,7 +351,12 @@ extern "C" int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_
   FF_CHECK_ARG(!use_mask || (shift_h > 0 && shift_w > 0), "ff_window_attn_bf16s: mask needs a shift");
   AttnBfParams p;
   p.qkv = qkv; p.out = out; p.biasT = biasT; p.ldq = ldq; p.ldo = ldo;
-  p.rel = rel_table; p.rel_w = 2 * ww - 1; p.rel_n = (2 * wh - 1) * (2 * ww - 1); p.lkw = 0;
+  // rel_table layouts: keys == query window: T [heads][(2wh-1)(2ww-1)] as stored by the reference.  Overlapping keys: the table
+  // ROTATED by m = -(minimum index) = ((wh-1) - a)(rel_w + 1) with a = wh - kh + 1, so that the kernel's index
+  //   kofs[key] + rel_base - qy rel_w - qx,   rel_base = m + a (rel_w + 1),   is always in [0, rel_n)  (prep.pack_rel_overlap).
+  p.rel = rel_table; p.rel_w = ww + kw - 1; p.rel_n = (wh + kh - 1) * (ww + kw - 1); p.lkw = 0;
+  p.rel_gen = rel_gen ? 1 : 0;
+  p.rel_base = rel_gen ? ((wh - 1) - (wh - kh + 1)) * (p.rel_w + 1) + (wh - kh + 1) * (p.rel_w + 1) : 0;
   while ((1 << p.lkw) < kw) ++p.lkw;
   p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.o_off = o_off;
   p.B = B; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.wh = wh; p.ww = ww; p.kh = kh; p.kw = kw;
@@ -342,7 +368,7 @@ extern "C" int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_
   const long long nblk = (long long)B * p.nwx * p.nwy * heads;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_window_attn_bf16s: grid too large");
   FF_CHECK_ARG((long long)B * H * W < (1LL << 31), "ff_window_attn_bf16s: too many tokens");
-  const size_t lds = (size_t)2 * AKC * KROWB + (size_t)2 * 32 * VROWB + (size_t)2 * p.nkpad * 4 + (rel_table ? (size_t)p.rel_n * 4 : 0);
+  const size_t lds = (size_t)2 * AKC * KROWB + (size_t)2 * 32 * VROWB + (size_t)2 * p.nkpad * 4 + (rel_table ? (size_t)p.rel_n * 4 : 0) + (rel_gen ? (size_t)p.nkpad * 4 : 0);
   FF_CHECK_ARG(lds <= 64 * 1024, "ff_window_attn_bf16s: window too large for the LDS image");
   if (nterms == 3)
     hipLaunchKernelGGL(window_attn_bf16_kernel<3>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);

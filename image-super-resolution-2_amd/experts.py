@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from .prep import (pack_conv, pack_dw, bn_scale_shift, fold_bn_after_conv, pack_token_mlp, pack_token_linear, pack_naf_ffn,
-                   pack_win_attn, pack_win_rel, pack_token_projmlp, pack_chan_qkv, pack_token_linear_gated)
+                   pack_win_attn, pack_win_rel, pack_token_projmlp, pack_chan_qkv, pack_token_linear_gated, pack_rel_overlap)
 
 T = torch.Tensor
 SD = Dict[str, T]
@@ -147,7 +147,7 @@ class HatHIP:
             tbl = w(q + "relative_position_bias_table")
             self.ocab.append(dict(
                 n1=(w(q + "norm1.weight"), w(q + "norm1.bias")), qkv=lin(q + "qkv"), proj=lin(q + "proj"),
-                bias=tbl[rpi_oca].reshape(n, nk, heads).permute(2, 1, 0).contiguous(),
+                bias=tbl[rpi_oca].reshape(n, nk, heads).permute(2, 1, 0).contiguous(), rel=pack_rel_overlap(tbl, ws, self.ows),
                 n2=(w(q + "norm2.weight"), w(q + "norm2.bias")), fc1=lin(q + "mlp.fc1"), fc2=lin(q + "mlp.fc2")))
             self.gconv.append((w.conv(f"layers.{g}.conv"), w(f"layers.{g}.conv.bias")))
         self.norm = (w("norm.weight"), w("norm.bias"))
@@ -207,7 +207,8 @@ class HatHIP:
             qkv = ops.linear(ops.layernorm(x, *blk["n1"]), *blk["qkv"])
         att = ops.empty_like_rows(x)
         ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
-                        kwin=(self.ows, self.ows), shift=(0, 0), use_mask=False, heads=self.heads, d=d, scale=d ** -0.5)
+                        kwin=(self.ows, self.ows), shift=(0, 0), use_mask=False, heads=self.heads, d=d, scale=d ** -0.5,
+                        rel_table=blk["rel"] if _REL_BIAS else None)
         if _fast() and _PROJ_MLP:
             return ops.token_projmlp(att, x, _pm(blk), blk["n2"][0], blk["n2"][1])
         x = ops.token_linear(att, _tl(blk, "proj"), res=x) if _fast() else ops.linear(att, *blk["proj"], res=x)

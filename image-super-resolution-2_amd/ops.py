@@ -309,7 +309,13 @@ def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int,
                                        _stream()))
     else:
         relp = None
-        if rel_table is not None and tuple(kwin) == tuple(win) and win[1] & (win[1] - 1) == 0 and win[1] >= 8:
+        if rel_table is not None and tuple(kwin) != tuple(win):
+            # overlapping keys: the rotated table of prep.pack_rel_overlap, gathered in the kernel through a per-key offset table
+            n = (win[0] + kwin[0] - 1) * (win[1] + kwin[1] - 1)
+            if tuple(rel_table.shape) != (heads, n) or not rel_table.is_contiguous() or kwin[1] % 8 or tuple(shift) != (0, 0):
+                raise _lib.FFError(f"window_attn: overlapping-window rel_table must be [heads, {n}] (prep.pack_rel_overlap), kw % 8 == 0, no shift")
+            relp = rel_table.data_ptr()
+        elif rel_table is not None and tuple(kwin) == tuple(win) and win[1] & (win[1] - 1) == 0 and win[1] >= 8:
             if tuple(rel_table.shape) != (heads, (2 * win[0] - 1) * (2 * win[1] - 1)) or not rel_table.is_contiguous():
                 raise _lib.FFError("window_attn: rel_table must be [heads, (2wh-1)*(2ww-1)]")
             relp = rel_table.data_ptr()

@@ -102,6 +102,21 @@ def pack_conv3x3_halo(wp: T, cin: int, bn: int) -> T:
     return img.contiguous()
 
 
+def pack_rel_overlap(table: T, wh: int, kh: int) -> T:
+    """Relative-position table of an OVERLAPPING window attention (HAT OCAB: hat_arch.py:882-899 builds the index with the offset
+    a = wh - kh + 1 < 0, so the reference gathers with negative indices that PyTorch wraps) -> [heads][n] rotated so that the
+    kernel's non-negative index i = m + (original index) reads U[i] = T[(i - m) mod n]; m = ((wh-1) - a) * (rel_w + 1).
+    table: [(wh+kh-1)^2, heads] as stored in the checkpoint (square windows)."""
+    rel_w = wh + kh - 1
+    n = rel_w * rel_w
+    if tuple(table.shape[:1]) != (n,):
+        raise ValueError(f"pack_rel_overlap: expected a table of {n} rows, got {tuple(table.shape)}")
+    a = wh - kh + 1
+    m = ((wh - 1) - a) * (rel_w + 1)
+    idx = (torch.arange(n, device=table.device) - m) % n
+    return table[idx].t().contiguous()
+
+
 def pack_token_linear(w: T, b: Optional[T]) -> dict:
     """Weights of ff_token_linear: [N, K<=192] -> bf16 [NT][2][32][kpad] hi/lo tiles (kpad = 64/128/192), bias padded."""
     N, K = w.shape

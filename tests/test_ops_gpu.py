@@ -335,6 +335,13 @@ def test_window_attn_ocab(dev, gemm_mode):
     vh = kvw[1].reshape(-1, ows * ows, heads, d).transpose(1, 2)
     o = O._softmax_attn(qh, kh, vh, bias, None).transpose(1, 2).reshape(-1, ws * ws, C)
     close(out, O._win_merge(o, ws, ws, H, W), GEMM_TOL[gemm_mode], "ocab")
+    if gemm_mode != "f32":          # the same bias gathered in the kernel from the rotated (ws+ows-1)^2 table: bit-identical
+        from isr2_amd.prep import pack_rel_overlap
+        out2 = torch.zeros(1, H, W, C, device=dev)
+        ops.window_attn(qkv, out2, bias.transpose(1, 2).contiguous(), q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W,
+                        win=(ws, ws), kwin=(ows, ows), shift=(0, 0), use_mask=False, heads=heads, d=d, scale=d ** -0.5,
+                        rel_table=pack_rel_overlap(table, ws, ows))
+        assert torch.equal(out, out2), "overlapping-window relative-position gather differs from the expanded table"
 
 
 @pytest.mark.parametrize("H,W,shifted", [(32, 64, False), (48, 48, True), (64, 32, True)])
