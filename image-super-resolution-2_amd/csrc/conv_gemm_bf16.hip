@@ -31,6 +31,7 @@ struct ConvBfParams {
   const float* bias;
   const float* mul;
   const float* res;
+  const float* kmul;   // optional [Cin] scale of the INPUT channels (1x1 only): out = W (kmul * a) -- NAFNet's conv3(x * sca)
   float* out;
   int B, H, W, Cin, ldi;
   int Ho, Wo, Cout, ldo, ldr;
@@ -41,6 +42,7 @@ struct ConvBfParams {
   float alpha;
   int shuffle;
   int vec_out;     // 16-byte epilogue: no shuffle, Cout % 4 == 0, 16-byte aligned out / res rows
+  int gate;        // shuffle == 1: SimpleGate in the epilogue, out[m][j] = y[m][2j] * y[m][2j+1] (Cout / 2 channels out)
 };
 
 // BKB = k-values per chunk (one barrier per chunk).  32: the original form.  64 (r2): twice the MFMAs between barriers -- the
@@ -118,6 +120,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16_kernel(ConvBfPar
         if (kok && a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
           v = *reinterpret_cast<const f32x4*>(p.in + ((long long)(a_b[i] * p.H + iy) * p.W + ix) * p.ldi + ci);
         ra[i] = v;
+      }
+      if (p.kmul && kok) {                            // (1x1: ci is the input channel; the launcher checks Cin % 4 == 0)
+        const f32x4 km = *reinterpret_cast<const f32x4*>(p.kmul + ci);
+#pragma unroll
+        for (int i = 0; i < AQ; ++i) ra[i] *= km;
       }
     } else {
 #pragma unroll
@@ -227,6 +234,36 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16_kernel(ConvBfPar
   auto epilogue = [&](auto ACTC) {
     constexpr int ACT = decltype(ACTC)::value;
     const bool has_res = p.res != nullptr;
+    if (p.gate) {
+      // SimpleGate (nafnet_arch.py:28-31, 100-104) on interleaved columns: the caller orders the weight rows so that the two halves of
+      // the reference's chunk(2, dim=1) alternate (2j <- j, 2j+1 <- j + C); a lane then multiplies adjacent columns of the
+      // transposed 32 x 32 tile and stores four consecutive product channels: the 2C-wide tensor never reaches memory.
+      float* tr = reinterpret_cast<float*>(smem) + wid * (32 * 36);
+      const int grow = lane >> 2, seg = lane & 3;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wc * TN + j * 32 + l31;
+        const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+        const int nq = (n0 + wc * TN + j * 32) / 2 + 4 * seg;      // first of this lane's four output channels
+        const bool nqok = nq < p.Cout / 2;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int mb = m0 + wr * TM + i * 32;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + l31] = acc[i][j][r] + bv;
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+            const int row = grow + 16 * pass;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(tr + row * 36 + 8 * seg);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(tr + row * 36 + 8 * seg + 4);
+            const f32x4 o = {a[0] * a[1], a[2] * a[3], b2[0] * b2[1], b2[2] * b2[3]};
+            const int m = mb + row;
+            if (nqok && m < p.M) *reinterpret_cast<f32x4*>(p.out + (long long)m * p.ldo + nq) = o;
+          }
+        }
+      }
+      return;
+    }
     if (p.vec_out) {
       // 16-byte form: each 32(m) x 32(n) accumulator tile goes through a wave-private LDS patch (the staging buffers are
       // idle now) so a lane owns four consecutive channels of one row: float4 residual loads and stores, 8 whole
@@ -369,8 +406,9 @@ static int dispatch_bf(const ConvBfParams& p, bool vec4, int cfg, hipStream_t st
 extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_lo, int Kp, int Cp, const float* bias,
                                const float* mul, const float* res, float* out, int B, int H, int W, int Cin, int ldi,
                                int Ho, int Wo, int Cout, int ldo, int ldr, int KH, int KW, int sy, int sx, int py, int px,
-                               int act, float alpha, int shuffle, int nterms, int tile_hint, void* stream) {
+                               int act, float alpha, int shuffle, int nterms, int tile_hint, const float* kmul, void* stream) {
   FF_CHECK_ARG(in && w_hi && out, "ff_conv2d_bf16s: null pointer");
+  FF_CHECK_ARG(!kmul || (KH == 1 && KW == 1 && Cin % 4 == 0 && (((uintptr_t)kmul) & 15) == 0), "ff_conv2d_bf16s: kmul needs a 1x1 kernel, Cin %% 4 == 0 and a 16-byte aligned vector");
   FF_CHECK_ARG(nterms >= 1 && nterms <= 3 && (nterms < 3 || w_lo), "ff_conv2d_bf16s: nterms must be 1..3 (3 needs w_lo)");
   FF_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "ff_conv2d_bf16s: bad dims");
   FF_CHECK_ARG(ldi >= Cin, "ff_conv2d_bf16s: ldi %d < Cin %d", ldi, Cin);
@@ -378,13 +416,16 @@ extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_
   FF_CHECK_ARG(Kp % 32 == 0 && Kp >= KH * KW * Cin, "ff_conv2d_bf16s: Kp must be K rounded up to 32");
   FF_CHECK_ARG(Cp == 0 || (Cp % 32 == 0 && Cp >= Cin && Kp == KH * KW * Cp), "ff_conv2d_bf16s: TAP layout needs Kp == taps * Cp, Cp = ceil32(Cin)");
   FF_CHECK_ARG((((uintptr_t)w_hi) & 15) == 0 && (!w_lo || (((uintptr_t)w_lo) & 15) == 0), "ff_conv2d_bf16s: weight planes must be 16-byte aligned");
-  FF_CHECK_ARG(shuffle == 0 || shuffle == 2, "ff_conv2d_bf16s: shuffle must be 0 or 2");
-  FF_CHECK_ARG(shuffle == 0 || Cout % 4 == 0, "ff_conv2d_bf16s: shuffle needs Cout %% 4 == 0");
-  FF_CHECK_ARG(ldo >= (shuffle ? Cout / 4 : Cout), "ff_conv2d_bf16s: ldo too small");
+  FF_CHECK_ARG(shuffle == 0 || shuffle == 1 || shuffle == 2, "ff_conv2d_bf16s: shuffle must be 0, 1 (SimpleGate pair product) or 2 (PixelShuffle)");
+  FF_CHECK_ARG(shuffle != 2 || Cout % 4 == 0, "ff_conv2d_bf16s: shuffle needs Cout %% 4 == 0");
+  FF_CHECK_ARG(shuffle != 1 || (Cout % 8 == 0 && !res && !mul && act == 0 && alpha == 1.f && ldo % 4 == 0 && (((uintptr_t)out) & 15) == 0),
+               "ff_conv2d_bf16s: the pair-product epilogue needs Cout %% 8 == 0, no residual / scale / activation and 16-byte aligned output rows");
+  FF_CHECK_ARG(ldo >= (shuffle == 2 ? Cout / 4 : shuffle == 1 ? Cout / 2 : Cout), "ff_conv2d_bf16s: ldo too small");
   FF_CHECK_ARG(!res || ldr >= (shuffle ? Cout / 4 : Cout), "ff_conv2d_bf16s: ldr too small");
   FF_CHECK_ARG((long long)B * Ho * Wo < (1LL << 31), "ff_conv2d_bf16s: M overflows int");
   ConvBfParams p;
   p.in = in; p.w_hi = (const __bf16*)w_hi; p.w_lo = (const __bf16*)w_lo; p.bias = bias; p.mul = mul; p.res = res; p.out = out;
+  p.kmul = kmul; p.gate = shuffle == 1 ? 1 : 0;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.ldi = ldi;
   p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.ldo = ldo; p.ldr = ldr;
   p.KH = KH; p.KW = KW; p.sy = sy; p.sx = sx; p.py = py; p.px = px;
@@ -394,6 +435,7 @@ extern "C" int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_
               (!res || (ldr % 4 == 0 && (((uintptr_t)res) & 15) == 0));
   const bool vec4 = (Cin % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)in & 15) == 0);
   FF_CHECK_ARG(Cp == 0 || vec4, "ff_conv2d_bf16s: TAP layout needs Cin %% 4 == 0 and 16-byte aligned rows");
+  FF_CHECK_ARG(!kmul || vec4, "ff_conv2d_bf16s: kmul needs 16-byte aligned input rows");
   hipStream_t st = (hipStream_t)stream;
   int cfg = tile_hint;
   if (cfg <= 0) {

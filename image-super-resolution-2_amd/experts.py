@@ -501,14 +501,25 @@ class NafnetHIP:
             t = ops.linear(ops.layernorm(x, *k["n1"], eps=1e-6), *k["c1"])
         g, pooled = ops.dwconv3_gate_pool(t, *k["c2"])                       # conv2 + SimpleGate + SCA pool sums
         sca = ops.vec_mlp(pooled, *k["sca"], None)                           # [1,c]
-        w3 = ops.mix2(k["c3"][0], ca=sca.reshape(-1))                        # conv3(g * sca) == (W3 . diag(sca)) g
-        y = ops.linear(g, w3, k["c3"][1], res=x, mul=k["beta"], dynamic_w=True)
+        nf = ops.gemm_mode() != "f32"                                        # the split-bf16 GEMM carries both NAFBlock fusions
+        if nf:                                                               # conv3(g * sca): the scale rides on the A operand
+            y = ops.linear(g, *k["c3"], res=x, mul=k["beta"], kmul=sca.reshape(-1))
+        else:
+            w3 = ops.mix2(k["c3"][0], ca=sca.reshape(-1))                    # conv3(g * sca) == (W3 . diag(sca)) g
+            y = ops.linear(g, w3, k["c3"][1], res=x, mul=k["beta"], dynamic_w=True)
         if flash:
             if "ffn_pk" not in k:
                 k["ffn_pk"] = pack_naf_ffn(k["c4"][0], k["c4"][1], k["c5"][0], k["c5"][1])
             return ops.naf_ffn(y, k["ffn_pk"], k["n2"][0], k["n2"][1], k["gamma"])
-        t = ops.linear(ops.layernorm(y, *k["n2"], eps=1e-6), *k["c4"])
-        g = ops.fma3(None, t[..., :c], t[..., c:])
+        if nf:                                                               # conv4 + SimpleGate in one launch: the 2c-wide tensor stays on chip
+            if "c4i" not in k:                                               # rows interleaved: 2j <- j, 2j+1 <- j + c (chunk(2, dim=1) halves)
+                w4, b4 = k["c4"]
+                k["c4i"] = (torch.stack((w4[:c], w4[c:]), dim=1).reshape(2 * c, -1).contiguous(),
+                            torch.stack((b4[:c], b4[c:]), dim=1).reshape(-1).contiguous())
+            g = ops.linear(ops.layernorm(y, *k["n2"], eps=1e-6), *k["c4i"], gate_pairs=True)
+        else:
+            t = ops.linear(ops.layernorm(y, *k["n2"], eps=1e-6), *k["c4"])
+            g = ops.fma3(None, t[..., :c], t[..., c:])
         return ops.linear(g, *k["c5"], res=y, mul=k["gamma"])
 
     def forward(self, lr: T, taps: Optional[dict] = None, feats: Optional[dict] = None) -> T:

@@ -252,7 +252,7 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
         _lib.check(_L().ff_conv2d_bf16s(xp, hi.data_ptr(), lo.data_ptr() if lo is not None else None, Kp, Cp, _ptr(bias), _ptr(mul),
                                         rp, op, B, H, W, Cin, ldi, Ho, Wo, Cout, ldo, ldr, KH, KW, stride[0], stride[1],
                                         pad[0], pad[1], ACT[act], float(alpha), shuffle, GEMM_MODES[_GEMM_MODE], tile_hint,
-                                        _stream()))
+                                        None, _stream()))
     _note(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, 4.0 * (_numel(x, w, out, res)))
     if want_pool:
         return out, pool_mean(out)
@@ -260,17 +260,22 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
 
 
 def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] = None, mul: Optional[T] = None,
-           alpha: float = 1.0, out: Optional[T] = None, dynamic_w: bool = False) -> T:
-    """x [..., K] rows view, w [N, K] -> [..., N]."""
+           alpha: float = 1.0, out: Optional[T] = None, dynamic_w: bool = False, kmul: Optional[T] = None,
+           gate_pairs: bool = False) -> T:
+    """x [..., K] rows view, w [N, K] -> [..., N].  kmul [K]: scale of the input channels (W (kmul * x); split-bf16 modes).
+    gate_pairs: SimpleGate in the epilogue, [..., N / 2] out with out[j] = y[2j] * y[2j+1] (rows of w interleaved by the caller)."""
     xp, ldi, rows, K = rows_view(x, "linear.x")
     N = w.shape[0]
     if w.dim() != 2 or w.shape[1] != K or not w.is_contiguous():
         raise _lib.FFError(f"linear: weight must be [N, {K}], got {tuple(w.shape)}")
-    oshape = tuple(x.shape[:-1]) + (N,)
+    if (kmul is not None or gate_pairs) and _GEMM_MODE == "f32":
+        raise _lib.FFError("linear: kmul / gate_pairs exist in the split-bf16 kernels only")
+    No = N // 2 if gate_pairs else N
+    oshape = tuple(x.shape[:-1]) + (No,)
     if out is None:
         out = empty_rows(oshape, x.device)
     op, ldo, orows, oc = rows_view(out, "linear.out")
-    if orows != rows or oc != N:
+    if orows != rows or oc != No:
         raise _lib.FFError("linear: out shape mismatch")
     rp, ldr = None, 0
     if res is not None:
@@ -283,10 +288,12 @@ def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] =
     else:
         aligned = (ldi % 4 == 0) and (xp % 16 == 0)
         hi, lo, Kp, Cp, _ = _split_weight(w, dynamic_w, K if aligned else 0)
+        if kmul is not None and (kmul.numel() != K or not kmul.is_contiguous()):
+            raise _lib.FFError(f"linear: kmul must be a contiguous [{K}] vector")
         _lib.check(_L().ff_conv2d_bf16s(xp, hi.data_ptr(), lo.data_ptr() if lo is not None else None, Kp, Cp, _ptr(bias), _ptr(mul),
                                         rp, op, 1, 1, rows, K, ldi, 1, rows, N, ldo, ldr, 1, 1, 1, 1, 0, 0, ACT[act],
-                                        float(alpha), 0, GEMM_MODES[_GEMM_MODE], 0, _stream()))
-    _note(2.0 * rows * N * K, 4.0 * (rows * K + N * K + rows * N * (2 if res is not None else 1)))
+                                        float(alpha), 1 if gate_pairs else 0, GEMM_MODES[_GEMM_MODE], 0, _ptr(kmul), _stream()))
+    _note(2.0 * rows * N * K, 4.0 * (rows * K + N * K + rows * No * (2 if res is not None else 1)))
     return out
 
 

@@ -50,11 +50,14 @@ int ff_conv2d(const float* in, const float* w, const float* bias, const float* m
  * accumulator.  nterms 3 = fp32-grade (~1e-5 rel), 2 = exact activations x bf16 weights, 1 = plain bf16.
  * w_hi / w_lo are bf16 planes [Cout][Kp] made by ff_split_bf16 (lo may be NULL for nterms < 3), zero filled, in one of
  * two K layouts: flat (Cp = 0, Kp = ceil32(KH*KW*Cin)) or per-tap padded (Cp = ceil32(Cin), Kp = KH*KW*Cp; needs
- * Cin % 4 == 0).  Everything else as ff_conv2d. */
+ * Cin % 4 == 0).  Everything else as ff_conv2d, plus two fusions of NAFBlock (nafnet_arch.py:88-106):
+ *   kmul (optional, 1x1 only): [Cin] scale of the input channels, out = W (kmul * a) + ... -- conv3(x * sca) without rescaling W;
+ *   shuffle = 1: SimpleGate in the epilogue, out[m][j] = y[m][2j] * y[m][2j+1] with y = A w^T + bias (Cout / 2 channels out; the
+ *   caller interleaves the weight rows of the two chunk(2) halves; no residual / scale / activation). */
 int ff_conv2d_bf16s(const float* in, const void* w_hi, const void* w_lo, int Kp, int Cp, const float* bias, const float* mul,
                     const float* res, float* out, int B, int H, int W, int Cin, int ldi, int Ho, int Wo, int Cout,
                     int ldo, int ldr, int KH, int KW, int sy, int sx, int py, int px, int act, float alpha, int shuffle,
-                    int nterms, int tile_hint, void* stream);
+                    int nterms, int tile_hint, const float* kmul, void* stream);
 int ff_split_bf16(const float* w, int N, int K, int Kp, int Cin, int Cp, void* hi, void* lo, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution for small channel counts (csrc/conv3x3_small.hip): Cin <= 64, Cout <= 16, exact fp32 on

@@ -177,6 +177,35 @@ def test_gemm_tile_forms_agree_with_torch(dev, hint, M, K, N, k):
         ops.set_gemm_mode(prev)
 
 
+@pytest.mark.parametrize("M,K,N", [(4096, 1024, 2048), (1000, 256, 512), (333, 64, 128)])
+def test_linear_input_scale_and_simple_gate_epilogue(dev, M, K, N):
+    """The two NAFBlock fusions of the split-bf16 GEMM (nafnet_arch.py:88-106): conv3(x * sca) as a scale on the A operand, and
+    conv4 + SimpleGate with the chunk(2) halves interleaved so that the product happens in the epilogue."""
+    from isr2_amd import ops
+    prev = ops.gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        x = rnd(M, K, dev=dev, seed=130)
+        w = rnd(N, K, dev=dev, seed=131, scale=1.0 / math.sqrt(K))
+        b = rnd(N, dev=dev, seed=132, scale=0.1)
+        km = rnd(K, dev=dev, seed=133) * 0.5 + 1.0
+        res = rnd(M, N, dev=dev, seed=134)
+        mul = rnd(N, dev=dev, seed=135)
+        close(ops.linear(x, w, b, res=res, mul=mul, kmul=km), res + mul * F.linear(x * km, w, b), GEMM_TOL["bf16x3"], "kmul")
+        c = N // 2
+        wi = torch.stack((w[:c], w[c:]), dim=1).reshape(N, K).contiguous()
+        bi = torch.stack((b[:c], b[c:]), dim=1).reshape(-1).contiguous()
+        y = F.linear(x, w, b)
+        got = ops.linear(x, wi, bi, gate_pairs=True)
+        assert got.shape == (M, c)
+        close(got, y[:, :c] * y[:, c:], 2 * GEMM_TOL["bf16x3"], "simple gate epilogue")
+        wide = torch.zeros(M, c + 12, device=dev)                       # into a channel slice of a wider buffer
+        ops.linear(x, wi, bi, gate_pairs=True, out=wide[:, 4:4 + c])
+        assert torch.equal(wide[:, 4:4 + c], got) and wide[:, :4].abs().max() == 0 and wide[:, 4 + c:].abs().max() == 0
+    finally:
+        ops.set_gemm_mode(prev)
+
+
 @pytest.mark.parametrize("M", [65536, 1000, 77])
 def test_token_mlp_fused(dev, M):
     """LN + fc1 + GELU + fc2 + residual in one launch (bf16x3) against the PyTorch fp32 chain."""
