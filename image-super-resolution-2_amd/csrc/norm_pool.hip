@@ -217,9 +217,17 @@ __global__ __launch_bounds__(256) void vec_mlp_kernel(const float* __restrict__ 
       if (lane == 0) out[(long long)b * Cout + o] = ff_act(s + (b2 ? b2[o] : 0.f), act2) * post;
     }
   } else {
+    const bool v4 = (Cin & 3) == 0 && (((uintptr_t)W1) & 15) == 0;       // NAFNet's SCA at 512 / 1024 channels: 16-byte weight loads
     for (int o = blockIdx.x * 4 + wid; o < Ch; o += gridDim.x * 4) {
       float s = 0.f;
-      for (int i = lane; i < Cin; i += 64) s += W1[(long long)o * Cin + i] * xin[i];
+      if (v4) {
+        for (int i = 4 * lane; i < Cin; i += 256) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(W1 + (long long)o * Cin + i);
+          s += (wv[0] * xin[i] + wv[1] * xin[i + 1]) + (wv[2] * xin[i + 2] + wv[3] * xin[i + 3]);
+        }
+      } else {
+        for (int i = lane; i < Cin; i += 64) s += W1[(long long)o * Cin + i] * xin[i];
+      }
       s = wave_sum(s);
       if (lane == 0) out[(long long)b * Ch + o] = ff_act(s + (b1 ? b1[o] : 0.f), act1) * post;
     }
@@ -233,7 +241,7 @@ extern "C" int ff_vec_mlp(const float* in, int B, int Cin, const float* W1, cons
   FF_CHECK_ARG(!W2 || Cout > 0, "ff_vec_mlp: bad Cout");
   const int nout = W2 ? Cout : Ch;
   int gx = (nout + 3) / 4;
-  if (gx > 64) gx = 64;
+  if (gx > 256) gx = 256;                          // one wave per output row up to 1024 rows: the 4 MB SCA matrix is read by every CU at once
   hipLaunchKernelGGL(vec_mlp_kernel, dim3(gx, B), dim3(256), (size_t)(Cin + Ch) * 4, (hipStream_t)stream, in, Cin, W1, b1, Ch,
                      act1, W2, b2, Cout, act2, post, out);
   FF_LAUNCH_CHECK("ff_vec_mlp");
