@@ -8,7 +8,7 @@ leading dims collapse to a single row stride (e.g. a channel slice t[..., a:b] o
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -121,11 +121,70 @@ def empty_like_rows(x: T) -> T:
     return empty_rows(tuple(x.shape), x.device)
 
 
+class PreparedWeights:
+    """Kernel-side images of weight tensors (bf16 hi/lo planes, LDS tile images, interleaved bias tables), built once per weight
+    and kind.  An explicit registry instead of ad-hoc attributes on the tensors: it is thread-safe, it can be enumerated (the plan
+    exporter ships these images), entries die with their weight (weak references), and `clear()` releases the device memory."""
+
+    def __init__(self):
+        import threading
+        self._d: Dict[Tuple[int, str], tuple] = {}
+        self._lock = threading.Lock()
+
+    def get(self, w: T, kind: str, build):
+        key = (id(w), kind)
+        with self._lock:
+            ent = self._d.get(key)
+        if ent is not None and ent[0]() is w:
+            return ent[1]
+        val = build()
+        import weakref
+        ref = weakref.ref(w, lambda _r, key=key: self._d.pop(key, None))
+        with self._lock:
+            self._d[key] = (ref, val)
+        return val
+
+    def peek(self, w: T, kind: str):
+        ent = self._d.get((id(w), kind))
+        return ent[1] if ent is not None and ent[0]() is w else None
+
+    def put(self, w: T, kind: str, val):
+        self._d.pop((id(w), kind), None)
+        return self.get(w, kind, lambda: val)
+
+    def of(self, w: T):
+        """Every prepared image of this weight: [(kind, value)]."""
+        with self._lock:
+            return [(k[1], e[1]) for k, e in self._d.items() if k[0] == id(w) and e[0]() is w]
+
+    def nbytes(self) -> int:
+        tot = 0
+
+        def walk(v):
+            nonlocal tot
+            if isinstance(v, torch.Tensor):
+                tot += v.numel() * v.element_size()
+            elif isinstance(v, (tuple, list)):
+                for u in v:
+                    walk(u)
+        with self._lock:
+            for e in self._d.values():
+                walk(e[1])
+        return tot
+
+    def clear(self):
+        with self._lock:
+            self._d.clear()
+
+
+PREPARED = PreparedWeights()
+
+
 def _split_weight(w: T, dynamic: bool, cin: int):
     """bf16 hi/lo planes [N][Kp] of a packed fp32 weight [N][taps*cin]; cached on the tensor object unless
     `dynamic`.  Per-tap padded (TAP) K layout when cin >= 32 and cin % 4 == 0, flat otherwise."""
     nterms = GEMM_MODES[_GEMM_MODE]
-    cached = None if dynamic else getattr(w, "_ff_split", None)
+    cached = None if dynamic else PREPARED.peek(w, "split")
     if cached is not None and cached[4] >= nterms:
         return cached
     N, K = w.shape
@@ -140,7 +199,7 @@ def _split_weight(w: T, dynamic: bool, cin: int):
                                   _stream()))
     ent = (hi, lo, Kp, Cp, nterms)
     if not dynamic:
-        w._ff_split = ent
+        PREPARED.put(w, "split", ent)
     return ent
 
 
@@ -215,10 +274,8 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
         # small-channel tail convolutions: exact fp32 on the VALU from an LDS halo tile (csrc/conv3x3_small.hip).  Measured on
         # MI355X at 1024 x 1024: 16->3 205 -> <70 us, 8->1 160 -> <70, 16->1 204 -> <70, 32->3 166 -> 95, 6->16 173 -> 126; but
         # 64->3 202 -> 370 and 32->16 187 -> 199 (VALU-bound: Cin * CT FMAs per pixel and tap), hence the Cin * CT <= 128 rule
-        ws = getattr(w, "_ff_small", None)
-        if ws is None:
-            from . import prep as _prep
-            ws = w._ff_small = _prep.pack_conv3x3_small(w, Cin)
+        from . import prep as _prep
+        ws = PREPARED.get(w, "small", lambda: _prep.pack_conv3x3_small(w, Cin))
         _lib.check(_L().ff_conv3x3_small(xp, ldi, ws.data_ptr(), ws.shape[2], _ptr(bias), rp, ldr, op, ldo, B, H, W, Cin, Cout, ACT[act],
                                          float(alpha), _stream()))
     elif _GEMM_MODE == "f32":
@@ -229,12 +286,12 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
           and not dynamic_w and Cin >= 32 and Cin % 4 == 0 and ldi % 4 == 0 and xp % 16 == 0
           and (Cout <= 64 or Cin >= 128 or 128 < Cout <= 192 or _HALO_ALL)   # measured (profiles/r01_conv3x3_halo_vs_igemm.txt); 64 -> 256 ties
           and H * W >= 1024 and xp != op and B * H * W * ldi < 2 ** 31):
-        img = getattr(w, "_ff_halo", None)
-        if img is None:
-            from . import prep as _prep
+        from . import prep as _prep
+
+        def _mk_halo():
             bn = _prep.halo_bn(Cout)
-            img = (_prep.pack_conv3x3_halo(w, Cin, bn), bn)
-            w._ff_halo = img
+            return (_prep.pack_conv3x3_halo(w, Cin, bn), bn)
+        img = PREPARED.get(w, "halo", _mk_halo)
         part = None
         if want_pool and B == 1 and shuffle == 0 and Cout <= img[1]:
             prow = int(_L().ff_conv3x3_halo_pool_rows(B, H, W, Cout, img[1]))
@@ -326,11 +383,8 @@ def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int,
             if tuple(rel_table.shape) != (heads, (2 * win[0] - 1) * (2 * win[1] - 1)) or not rel_table.is_contiguous():
                 raise _lib.FFError("window_attn: rel_table must be [heads, (2wh-1)*(2ww-1)]")
             relp = rel_table.data_ptr()
-        bq = getattr(biasT, "_ff_quad", None)
-        if bq is None:                              # load-time relayout, cached on the table
-            from . import prep as _prep
-            bq = _prep.quad_bias(biasT)
-            biasT._ff_quad = bq
+        from . import prep as _prep
+        bq = PREPARED.get(biasT, "quad", lambda: _prep.quad_bias(biasT))          # load-time relayout, once per table
         _lib.check(_L().ff_window_attn_bf16s(qp, ldq, q_off, k_off, v_off, op, ldo, o_off, bq.data_ptr(), B, H, W, Hp, Wp,
                                              win[0], win[1], kwin[0], kwin[1], shift[0], shift[1], int(use_mask), heads, d,
                                              float(scale), 1 if _GEMM_MODE == "bf16" else 3, relp, _stream()))

@@ -37,7 +37,7 @@ ALIGN = 256
 # recording
 def _walk_tensors(obj, path: str, out: Dict[int, Tuple[str, torch.Tensor]], seen: set):
     """Every CUDA tensor reachable from the model objects (lists / tuples / dicts / attributes, and the prepared planes that
-    ops.py caches on weight tensors as _ff_split / _ff_halo / _ff_quad)."""
+    ops.PREPARED holds for the weight tensors: split planes, halo / small-conv images, interleaved bias tables)."""
     if id(obj) in seen:
         return
     seen.add(id(obj))
@@ -45,9 +45,9 @@ def _walk_tensors(obj, path: str, out: Dict[int, Tuple[str, torch.Tensor]], seen
         if obj.is_cuda:
             st = obj.untyped_storage()
             out.setdefault(st.data_ptr(), (path, obj))
-        for a in ("_ff_split", "_ff_halo", "_ff_quad", "_ff_small"):
-            if hasattr(obj, a):
-                _walk_tensors(getattr(obj, a), f"{path}.{a}", out, seen)
+        from . import ops as _ops
+        for kind, val in _ops.PREPARED.of(obj):
+            _walk_tensors(val, f"{path}.<{kind}>", out, seen)
         return
     if isinstance(obj, dict):
         for k, v in obj.items():

@@ -111,7 +111,7 @@ def test_conv3x3_halo_matches_torch(dev, B, H, W, Cin, Cout, act):
         res = rnd(B, H, W, Cout, dev=dev, seed=64)
         wp = pack_conv(w)
         out = ops.conv2d(x, wp, b, ksize=(3, 3), pad=(1, 1), act=act, res=res, mul=mul, alpha=0.7)
-        assert getattr(wp, "_ff_halo", None) is not None, "halo kernel was not selected"
+        assert ops.PREPARED.peek(wp, "halo") is not None, "halo kernel was not selected"
         f = {"gelu": F.gelu, "relu": F.relu, "sigmoid": torch.sigmoid, "lrelu": lambda t: F.leaky_relu(t, 0.01), None: lambda t: t}[act]
         ref = res + 0.7 * mul * f(F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)).permute(0, 2, 3, 1)
         close(out, ref, GEMM_TOL["bf16x3"], "conv3x3 halo")
@@ -921,7 +921,7 @@ def test_conv3x3_small_matches_torch(dev, Cin, Cout, H, W, act, with_res):
             ref = ref + res
         wp = pack_conv(w)
         out = ops.conv2d(x, wp, b, ksize=(3, 3), pad=(1, 1), act=act, res=res, alpha=0.1)
-        assert getattr(wp, "_ff_small", None) is not None, "small-channel kernel was not selected"
+        assert ops.PREPARED.peek(wp, "small") is not None, "small-channel kernel was not selected"
         close(out, ref, 3e-6, "conv3x3 small")
     finally:
         ops.set_gemm_mode(prev)
