@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="time the eager Python launch loop instead of HIP-graph replay")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("FF_BENCH_LANES", "2")), choices=(1, 2),
+                    help="tiles in flight: 2 = consecutive steps replay on two lane streams (model.graphed_async, the plugin's tile pipeline), 1 = strictly one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the f32 / plain-bf16 side measurements")
     ap.add_argument("--tile", type=int, default=TILE)
@@ -243,8 +245,24 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
+    lanes = args.lanes if graph is not None else 1
+    if lanes == 2:
+        try:                                                 # capture both lane graphs outside the timed region
+            model.graphed_async(lr, 0)
+            model.graphed_async(lr, 1)
+            torch.cuda.synchronize()
+            log("two lane graphs captured")
+        except Exception as e:
+            print(f"[bench] lane capture failed ({type(e).__name__}: {e}); one tile at a time", file=sys.stderr)
+            lanes = 1
+            torch.cuda.synchronize()
+    nstep = [0]
+
     def step():
-        if graph is not None:
+        if lanes == 2:                                       # step i on lane i & 1: step i+1 starts while step i drains
+            model.graphed_async(lr, nstep[0] & 1)
+            nstep[0] += 1
+        elif graph is not None:
             graph.replay()
         else:
             model(lr)
@@ -365,14 +383,26 @@ def main():
                                    "seeded synthetic weights (172.3 M params), 1/f-noise tiles",
                        "tile": tile, "tiles_per_step_per_gpu": 1,
                        "parallelism": f"tile-sharded x{world}, weights {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'}-broadcast once ({bcast_s * 1e3:.1f} ms), no per-tile collectives",
-                       "launch": "hipGraph replay" if graph is not None else "eager"},
+                       "launch": "hipGraph replay" if graph is not None else "eager",
+                       "tiles_in_flight": lanes},
             "path_tflops": world * args.steps * flop_per_tile / elapsed / 1e12,
             "roofline": roof, "stage_ms_per_tile": stages, "kernel_breakdown_ms_per_tile": breakdown,
         }
         if world == 1 and not args.no_extra:
             log("side measurements: f32 and plain-bf16 contraction modes")
+            one_ms = None
+            if lanes == 2:                                   # the same tile strictly one after the other (latency of one tile)
+                for _ in range(2):
+                    graph.replay()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    graph.replay()
+                torch.cuda.synchronize()
+                one_ms = 1e3 * (time.perf_counter() - t1) / args.steps
             extra = {"note": "same workload and launch path in the other contraction modes; PSNR is against the REFERENCE's output "
                              "on bench tile 100 (tests/golden/t256_nat.npz)",
+                     "one_tile_at_a_time_ms": one_ms,
                      ops.gemm_mode(): {"ms_per_step": line["ms_per_step"], "output_MPix_s": value,
                                        "psnr_vs_reference_golden_dB": golden_psnr(model, dev) if tile == TILE else None}}
             for mode in ("f32", "bf16"):

@@ -486,7 +486,7 @@ class NafnetHIP:
         """[B,Hp,Wp,3] buffer whose padding (check_image_size, nafnet_arch.py:220-225: zeros right/bottom) was zeroed ONCE when
         the buffer was made; the resampler only ever writes the top-left H x W region, so no fill runs per forward.  Kept per
         shape for the life of the model: a captured HIP graph may hold the address."""
-        key = (B, Hp, Wp, str(dev))
+        key = (B, Hp, Wp, str(dev), ops.lane())
         buf = self._inp.get(key)
         if buf is None:
             buf = self._inp[key] = torch.zeros((B, Hp, Wp, 3), device=dev, dtype=torch.float32)

@@ -297,7 +297,7 @@ class HierFusion:
         """[1,h,w,76] concat buffer whose channels 73..75 are zero (allocated zeroed once per size; never written again).
         One buffer per (role, size), kept for the life of the model: a HIP graph captured at one size keeps its address valid
         when a forward at another size comes in between."""
-        k = (key, h, w, str(dev))
+        k = (key, h, w, str(dev), ops.lane())
         buf = self._cat.get(k)
         if buf is None:
             buf = self._cat[k] = torch.zeros((1, h, w, 76), device=dev, dtype=torch.float32)

@@ -32,8 +32,9 @@ class FreqFusionHIP:
         self.multi_stream = os.environ.get("FF_STREAMS", "1") != "0"
         self._side = None
         self._marker = None                              # plan recording: called with "fork" / "join" around the three-stream section
-        self._graphs = {}                                # (B,h,w) -> (graph, static input, static output)
-        self.max_graphs = int(os.environ.get("FF_MAX_GRAPHS", "6"))
+        self._graphs = {}                                # (B,h,w[,lane]) -> (graph, static input, static output)
+        self._lanes = None                               # graphed_async: one replay stream per lane
+        self.max_graphs = int(os.environ.get("FF_MAX_GRAPHS", "8"))
         with torch.cuda.device(dev):
             self.hat = HatHIP(state_dict, dev)
             self.dat = DatHIP(state_dict, dev)
@@ -143,29 +144,60 @@ class FreqFusionHIP:
     @torch.no_grad()
     def graphed(self, lr: T) -> T:
         """forward(lr) replayed from a HIP graph cached per input shape (captured on the first call with that shape: one
-        warm-up on a side stream, then the capture).  The whole launch sequence -- ~1700 kernels on three streams -- becomes
+        warm-up on a side stream, then the capture).  The whole launch sequence -- ~1400 kernels on three streams -- becomes
         one hipGraphLaunch; tiles of one shape (io._tiled_forward, bench.py) replay the same graph.  The returned tensor is
         the graph's static output buffer: consume it (or clone it) before the next graphed() call of the same shape."""
-        lr = lr.to(self.dev, torch.float32)
-        key = tuple(lr.shape)
-        ent = self._graphs.get(key)
-        if ent is None:
-            if len(self._graphs) >= self.max_graphs:          # each graph pins its own activation pool: keep a few shapes only
-                self._graphs.pop(next(iter(self._graphs)))
-            with torch.cuda.device(self.dev):
-                static_in = lr.clone().contiguous()
-                cur = torch.cuda.current_stream()
-                side = torch.cuda.Stream(device=self.dev)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    self.forward(static_in)
-                cur.wait_stream(side)
-                torch.cuda.synchronize(self.dev)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    static_out = self.forward(static_in)
-            ent = self._graphs[key] = (graph, static_in, static_out)
-        graph, static_in, static_out = ent
+        graph, static_in, static_out = self._graph_for(lr, 0)
         static_in.copy_(lr, non_blocking=True)               # device-to-device memcpy into the captured input buffer
         graph.replay()
         return static_out
+
+    def _graph_for(self, lr: T, lane: int):
+        lr = lr.to(self.dev, torch.float32)
+        key = tuple(lr.shape) + ((lane,) if lane else ())
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= self.max_graphs:          # each graph pins its own activation pool: keep a few shapes only
+                torch.cuda.synchronize(self.dev)              # (a replay of the evicted graph may still be in flight on a lane)
+                self._graphs.pop(next(iter(self._graphs)))
+            from . import ops
+            ops.set_lane(lane)
+            try:
+                with torch.cuda.device(self.dev):
+                    static_in = lr.clone().contiguous()
+                    cur = torch.cuda.current_stream()
+                    side = torch.cuda.Stream(device=self.dev)
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        self.forward(static_in)
+                    cur.wait_stream(side)
+                    torch.cuda.synchronize(self.dev)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        static_out = self.forward(static_in)
+            finally:
+                ops.set_lane(0)
+            ent = self._graphs[key] = (graph, static_in, static_out)
+        return ent
+
+    def graphed_async(self, lr: T, lane: int):
+        """Two-deep tile pipeline: like graphed(), but the replay runs on the lane's own stream (lane 0 / 1, each with its own
+        captured graph, static buffers and persistent scratch), so the tail of one tile -- the fusion stack's small grids after the
+        three experts have joined -- overlaps the head of the next.  Returns (static output, event): wait for the event on the
+        consuming stream before reading the output; work the caller has queued on the current stream (the previous consumer of
+        this lane's output included) is ordered before the replay.  Tiles of one image are independent (io._tiled_forward)."""
+        if lane not in (0, 1):
+            raise _lib.FFError("graphed_async: lane must be 0 or 1")
+        graph, static_in, static_out = self._graph_for(lr, lane + 1)  # own graph + persistent scratch per lane (0 is the synchronous path's); first use captures on the CURRENT stream
+        if self._lanes is None:
+            self._lanes = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+        ls = self._lanes[lane]
+        ls.wait_stream(torch.cuda.current_stream())
+        src = lr.to(self.dev, torch.float32)
+        src.record_stream(ls)                                 # the caller may drop the tile before the lane has copied it
+        with torch.cuda.stream(ls):
+            static_in.copy_(src, non_blocking=True)
+            graph.replay()
+            ev = torch.cuda.Event()
+            ev.record(ls)
+        return static_out, ev

@@ -121,6 +121,20 @@ def empty_like_rows(x: T) -> T:
     return empty_rows(tuple(x.shape), x.device)
 
 
+# Replay lane (model.graphed_async): two captured graphs of one shape may be in flight at once, so every buffer that outlives a
+# forward (NAFNet's zero-padded input, the hierarchical fusion's concat buffers) is keyed by the lane that is being captured.
+_LANE = 0
+
+
+def lane() -> int:
+    return _LANE
+
+
+def set_lane(k: int) -> None:
+    global _LANE
+    _LANE = int(k)
+
+
 class PreparedWeights:
     """Kernel-side images of weight tensors (bf16 hi/lo planes, LDS tile images, interleaved bias tables), built once per weight
     and kind.  An explicit registry instead of ad-hoc attributes on the tensors: it is thread-safe, it can be enumerated (the plan

@@ -116,14 +116,42 @@ def _tiled_forward(model, lr_img, tile_size=64, overlap=8, scale=4, device="cuda
     blend = min(overlap * scale, st // 4)
     ramps = _ramp_table(st, blend, device)
     run = getattr(model, "graphed", None) if os.environ.get("FF_TILE_GRAPH", "1") != "0" else None
+    # Full-size tiles go through a two-deep pipeline (model.graphed_async: two captured graphs replayed on two lane streams), so the
+    # small-grid tail of one tile overlaps the head of the next; results are accumulated in tile order on the current stream, so the
+    # blend is bit-identical to the sequential loop.  FF_TILE_LANES=0 switches it off.
+    run_async = getattr(model, "graphed_async", None) if run is not None and os.environ.get("FF_TILE_LANES", "1") != "0" else None
+    pend = [None, None]
+
+    def blend_in(sr_tile, y, x):
+        th, tw = sr_tile.shape[-2:]
+        wy = ramps[(1 if y > 0 else 0) + (2 if y + tile_size < h else 0)]
+        wx = ramps[(1 if x > 0 else 0) + (2 if x + tile_size < w else 0)]
+        ops.tile_accum(sr_tile, wy[:th], wx[:tw], acc, wsum, y * scale, x * scale)
+
+    def consume(lane):
+        if pend[lane] is not None:
+            out, ev, y, x = pend[lane]
+            torch.cuda.current_stream().wait_event(ev)
+            blend_in(out, y, x)
+            pend[lane] = None
+
+    n = 0
     for y in _tile_positions(h, tile_size, step):
         for x in _tile_positions(w, tile_size, step):
             lr_tile = lr_img[:, :, y:y + tile_size, x:x + tile_size].contiguous()
+            if run_async is not None and tuple(lr_tile.shape[-2:]) == (tile_size, tile_size):
+                lane = n & 1
+                consume(lane)                              # tile n-2: its output buffer is about to be overwritten
+                out, ev = run_async(lr_tile, lane)
+                pend[lane] = (out, ev, y, x)
+                n += 1
+                continue
+            consume(n & 1)                                 # ragged edge tile: drain in tile order, then the plain path
+            consume((n + 1) & 1)
             sr_tile = run(lr_tile) if run is not None else model(lr_tile)
-            th, tw = sr_tile.shape[-2:]
-            wy = ramps[(1 if y > 0 else 0) + (2 if y + tile_size < h else 0)]
-            wx = ramps[(1 if x > 0 else 0) + (2 if x + tile_size < w else 0)]
-            ops.tile_accum(sr_tile, wy[:th], wx[:tw], acc, wsum, y * scale, x * scale)
+            blend_in(sr_tile, y, x)
+    consume(n & 1)
+    consume((n + 1) & 1)
     ops.tile_normalize(acc, wsum)
     return acc
 

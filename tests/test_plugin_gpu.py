@@ -250,6 +250,32 @@ def test_graphed_forward_is_bit_exact_and_survives_other_sizes(dev, hip_model):
     assert torch.equal(hip_model(a2), ga3)
 
 
+def test_two_lane_tile_pipeline_is_bit_exact(dev, hip_model, monkeypatch):
+    """model.graphed_async / io._tiled_forward with two tiles in flight (two captured graphs on two lane streams, lane-keyed
+    persistent buffers): the same bits as one tile at a time, on an image with full, right-edge, bottom-edge and corner tiles."""
+    import models.team29_FreqFusion.io as plug
+    lr = torch.from_numpy(np.random.default_rng(77).random((1, 3, 150, 200), dtype=np.float32)).to(dev)
+    monkeypatch.setenv("FF_TILE_LANES", "0")
+    ref = plug._tiled_forward(hip_model, lr, tile_size=64, overlap=8, scale=4, device=dev).clone()
+    monkeypatch.setenv("FF_TILE_LANES", "1")
+    got = plug._tiled_forward(hip_model, lr, tile_size=64, overlap=8, scale=4, device=dev)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    # the primitive itself: lanes return what graphed() returns, in any interleaving, and an eager forward in between is harmless
+    a = lr[:, :, :64, :64].contiguous()
+    b = lr[:, :, 64:128, 100:164].contiguous()
+    ra, rb = hip_model.graphed(a).clone(), hip_model.graphed(b).clone()
+    o0, e0 = hip_model.graphed_async(a, 0)
+    o1, e1 = hip_model.graphed_async(b, 1)
+    hip_model(b)
+    e0.synchronize()
+    e1.synchronize()
+    assert torch.equal(o0, ra) and torch.equal(o1, rb)
+    o0, e0 = hip_model.graphed_async(b, 0)
+    e0.synchronize()
+    assert torch.equal(o0, rb)
+
+
 def test_config4_image_through_the_plugin(tmp_path, dev, hip_model, monkeypatch, synth_sd):
     """BASELINE config 4's unit of work at world = 1: one 2040x1356 LR image through main(), both branches of the reference's
     policy (io.py:219-228).  (a) Whole image: fits in 288 GB -- output geometry, range, and agreement of the split-bf16 path
