@@ -78,22 +78,27 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
     // tensor.  S = x supplies the per-token gate sm -- its 11-unit first layer is one more 32-row weight tile (index NT of the
     // image, rows 11..31 zero) against S's own fragments -- and takes the per-channel gate cm; O = x2 takes sm.
     dma(p.NT, 1);
-    {
-      float v[TL_KS][8];
-      ff_wave_rows_to_frags<TL_KS / 4>(p.x, p.ldx, tok0, p.M, p.K, xs, lane, v);
-#pragma unroll
-      for (int st = 0; st < TL_KS; ++st)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const __bf16 h = (__bf16)v[st][j];
-          xh[st][j] = h;
-          xl[st][j] = (__bf16)(v[st][j] - (float)h);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                                           // tile 0 (slot 0) and the gate tile (slot 1) landed
+    // Two phases, so that at most one set of fragments is live (the one-phase form -- S fragments kept through the O passes and
+    // rewritten in place -- needed > 256 registers: 137 dwords of scratch per lane, ~70 MB of spill traffic per launch):
+    //   phase 1: S rows -> temporary fragments -> gate GEMM -> sm (one float per lane pair);
+    //   phase 2: S and O rows again, 64 channels per pass (S is an L2 hit now), combined in fp32 and split into the final fragments.
     float sm;
     {
+      bf16x8 th[TL_KS], tl[TL_KS];
+      {
+        float v[TL_KS][8];
+        ff_wave_rows_to_frags<TL_KS / 4>(p.x, p.ldx, tok0, p.M, p.K, xs, lane, v);
+#pragma unroll
+        for (int st = 0; st < TL_KS; ++st)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const __bf16 h = (__bf16)v[st][j];
+            th[st][j] = h;
+            tl[st][j] = (__bf16)(v[st][j] - (float)h);
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                                         // tile 0 (slot 0) and the gate tile (slot 1) landed
       const unsigned char* ap = smem + BUFB + l31 * TL_ROWB + 16 * hh;
       f32x16 ga;
 #pragma unroll
@@ -112,9 +117,9 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
           fl[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2) + WB);
         }
         __builtin_amdgcn_sched_barrier(0);
-        ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[st], ga, 0, 0, 0);
-        ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], ga, 0, 0, 0);
-        ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], ga, 0, 0, 0);
+        ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, tl[st], ga, 0, 0, 0);
+        ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, th[st], ga, 0, 0, 0);
+        ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, th[st], ga, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       float sacc = 0.f;
@@ -123,20 +128,31 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
       sacc += __shfl_xor(sacc, 32);
       sm = 1.0f / (1.0f + expf(-(sacc + p.gb2)));
     }
+    asm volatile("" ::: "memory");
     const int rr = lane >> 4, cq = (lane & 15) * 4;
 #pragma unroll
-    for (int pass = 0; pass < TL_KS / 4; ++pass) {                             // O rows, 64 channels per pass (S occupies the registers)
-      asm volatile("" ::: "memory");                                           // keep the passes apart: hipcc otherwise hoists all 24 row loads (96 VGPRs) above the gate GEMM and spills
-      f32x4 t[8];
+    for (int pass = 0; pass < TL_KS / 4; ++pass) {
+      asm volatile("" ::: "memory");                                           // keep the passes apart (no hoisting of all row loads)
+      f32x4 tS[8], tO[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = 4 * j + rr, c = 64 * pass + cq;
         const bool ok = tok0 + r < p.M && c < p.K;
-        const f32x4 u = *reinterpret_cast<const f32x4*>(p.x2 + (ok ? (tok0 + r) * p.ldx2 + c : 0));
-        t[j] = ok ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p.x + (ok ? (tok0 + r) * p.ldx + c : 0));
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(p.x2 + (ok ? (tok0 + r) * p.ldx2 + c : 0));
+        tS[j] = ok ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
+        tO[j] = ok ? w2 : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(xs + (4 * j + rr) * FF_XS_ROW + cq) = t[j];
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(xs + (4 * j + rr) * FF_XS_ROW + cq) = tS[j];
+      f32x4 sa[4], sb[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        sa[s4] = *reinterpret_cast<const f32x4*>(xs + l31 * FF_XS_ROW + 16 * s4 + 8 * hh);
+        sb[s4] = *reinterpret_cast<const f32x4*>(xs + l31 * FF_XS_ROW + 16 * s4 + 8 * hh + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(xs + (4 * j + rr) * FF_XS_ROW + cq) = tO[j];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int st = 4 * pass + s4, k0 = 16 * st + 8 * hh;
@@ -144,18 +160,20 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
         const f32x4 ob = *reinterpret_cast<const f32x4*>(xs + l31 * FF_XS_ROW + 16 * s4 + 8 * hh + 4);
         const int ka = k0 < p.K ? k0 : 0, kb = k0 + 4 < p.K ? k0 + 4 : 0;
         const f32x4 ca = *reinterpret_cast<const f32x4*>(p.cm + ka), cb = *reinterpret_cast<const f32x4*>(p.cm + kb);
+        bf16x8 nh, nl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float o = j < 4 ? oa[j & 3] : ob[j & 3], cmv = j < 4 ? ca[j & 3] : cb[j & 3];
-          // S is taken back from its own hi + lo split (2^-17 relative: the accuracy the split-bf16 product has anyway), so
-          // the fp32 copy of the rows does not have to stay in registers next to the fragments
-          const float sv = (float)xh[st][j] + (float)xl[st][j];
+          const float sv = j < 4 ? sa[s4][j & 3] : sb[s4][j & 3];
           const float f = (k0 + j < p.K) ? sv * cmv + o * sm : 0.f;
           const __bf16 h = (__bf16)f;
-          xh[st][j] = h;
-          xl[st][j] = (__bf16)(f - (float)h);
+          nh[j] = h;
+          nl[j] = (__bf16)(f - (float)h);
         }
-      }
+        xh[st] = nh;
+        xl[st] = nl;
+        asm volatile("" : "+v"(xh[st]), "+v"(xl[st]) : : "memory");            // the pass's fragments are FINISHED here: without this the
+      }                                                                        // scheduler issues every pass's loads first and converts last (raw rows of all passes live)
     }
   } else
   {
