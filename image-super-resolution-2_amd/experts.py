@@ -91,6 +91,10 @@ def _wf(blk: dict, heads: int, d: int) -> dict:
 # measured SLOWER on MI355X (120 vs 108 us per launch: the kernel is issue / LDS bound, not bandwidth bound), so the
 # expanded quad-interleaved table stays the default; FF_REL_BIAS=1 selects the gather.
 _REL_BIAS = os.environ.get("FF_REL_BIAS", "0") == "1"
+# OCAB (576 keys per window): FF_REL_OCAB=1 gathers the bias from the rotated compact table in LDS instead of streaming the expanded
+# one (3.5 MB per head).  Bit-identical, 430 MB less traffic per launch, but 314 vs 207 us on MI355X (two dependent LDS reads per score):
+# the expanded table stays the default.
+_REL_OCAB = os.environ.get("FF_REL_OCAB", "0") == "1"
 
 
 def _rel_index_sa(ws: int) -> T:
@@ -208,7 +212,7 @@ class HatHIP:
         att = ops.empty_like_rows(x)
         ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
                         kwin=(self.ows, self.ows), shift=(0, 0), use_mask=False, heads=self.heads, d=d, scale=d ** -0.5,
-                        rel_table=blk["rel"] if _REL_BIAS else None)
+                        rel_table=blk["rel"] if _REL_OCAB else None)
         if _fast() and _PROJ_MLP:
             return ops.token_projmlp(att, x, _pm(blk), blk["n2"][0], blk["n2"][1])
         x = ops.token_linear(att, _tl(blk, "proj"), res=x) if _fast() else ops.linear(att, *blk["proj"], res=x)
