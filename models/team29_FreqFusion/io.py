@@ -64,6 +64,12 @@ def _load_image(path: str, device=None) -> torch.Tensor:
     return torch.from_numpy(arr.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
 
 
+# zlib level of the written PNGs.  The reference saves with PIL's default (6); the pixels are what the challenge scores, and at level 6
+# ONE 8160x5424 output costs ~35 s of a CPU core against ~3.5 s of GPU time for the image.  Level 1 (OpenCV's default) is ~6x faster
+# for ~17 % larger files; FF_PNG_LEVEL=6 restores the reference's file sizes.  Decoded images are identical either way.
+PNG_LEVEL = int(os.environ.get("FF_PNG_LEVEL", "1"))
+
+
 def _save_image(tensor: torch.Tensor, path: str):
     """[1,3,H,W] -> clamp, *255, round-half-even, uint8 HWC PNG (reference io.py:71-76); converted on the device
     (ff_f32nchw_to_u8hwc) when the tensor lives there, so only the uint8 image is copied back."""
@@ -73,7 +79,7 @@ def _save_image(tensor: torch.Tensor, path: str):
         if tensor.dim() == 4:
             tensor = tensor.squeeze(0)
         arr = (tensor.clamp(0, 1).permute(1, 2, 0).numpy() * 255.0).round().astype(np.uint8)
-    Image.fromarray(arr).save(path, format="PNG")
+    Image.fromarray(arr).save(path, format="PNG", compress_level=PNG_LEVEL)
 
 
 def _tile_positions(n: int, tile: int, step: int):
@@ -258,7 +264,7 @@ class _HostPipeline:
     The calling thread owns every GPU call (H2D copy, kernels, D2H copy); a slot is reused only after the event that marks
     its last copy has completed.  Exceptions raised on a worker thread are re-raised on the calling thread."""
 
-    def __init__(self, paths, out_dir, device, n_slots: int = 3, n_writers: int = 2):
+    def __init__(self, paths, out_dir, device, n_slots: int = 5, n_writers: int = 4):
         self.paths, self.out_dir, self.device = list(paths), out_dir, device
         self.err = None
         self.in_free, self.in_ready = queue.Queue(), queue.Queue()
@@ -309,7 +315,7 @@ class _HostPipeline:
                 ev.synchronize()                                 # the D2H copy into this slot has finished
                 t0 = time.perf_counter()
                 arr = slot["buf"][:h * w * 3].view(h, w, 3).numpy()
-                Image.fromarray(arr).save(os.path.join(self.out_dir, name), format="PNG")
+                Image.fromarray(arr).save(os.path.join(self.out_dir, name), format="PNG", compress_level=PNG_LEVEL)
                 self.t_encode += time.perf_counter() - t0
                 self.out_free.put(slot)
         except BaseException as e:                               # noqa: BLE001
@@ -358,13 +364,19 @@ class _HostPipeline:
         self._check()
 
 
+# Graph capture costs two extra forwards and pins an activation pool; it pays where the Python launch loop (~1400 launches) is as long
+# as the GPU work -- images up to about 512 x 512 LR pixels.  A 2040 x 1356 image runs 2.9 s of GPU work per forward: launched eagerly.
+GRAPH_MAX_PIXELS = int(os.environ.get("FF_GRAPH_MAX_PIXELS", str(512 * 512)))
+
+
 def _forward_image(model, lr_img, img_name, device, seen_shapes):
     """Whole image, else 128/32 overlap tiles when the whole image does not fit (reference io.py:219-228).  Besides the
     allocator's 'out of memory', a kernel's own size limit (FFError, e.g. the direct-DFT row length) selects the tiles."""
     shape = tuple(lr_img.shape)
     try:
-        if seen_shapes is not None and hasattr(model, "graphed") and seen_shapes.get(shape, 0) >= 1:
-            sr = model.graphed(lr_img)                          # a shape that repeats replays its captured graph
+        small = shape[-1] * shape[-2] <= GRAPH_MAX_PIXELS
+        if small and seen_shapes is not None and hasattr(model, "graphed") and seen_shapes.get(shape, 0) >= 1:
+            sr = model.graphed(lr_img)                          # a (small) shape that repeats replays its captured graph
         else:
             sr = model(lr_img)
         if seen_shapes is not None:
