@@ -363,6 +363,25 @@ def main():
                               "compulsory_GB": 0.689 + 4 * 3 * (tile * tile + 16 * tile * tile) / 1e9,
                               "note": "hbm_GB_per_tile = PMC (2*FETCH_SIZE+WRITE_SIZE) summed over every kernel of one forward; "
                                       "compulsory = fp32 weights read once + LR in + SR out"}
+        # the conv / GEMM family launch by launch against the bound that applies to EACH launch: algorithmic intensity above the ridge
+        # (executable MFMA peak / HBM peak) -> MFMA-bound, below -> HBM-bound (NAFNet's 1x1 convolutions at 64 / 128 channels, the
+        # 3- and 9-channel heads of the fusion stack); the family entry above stays the undivided total
+        ridge = (peak / MFMA_PER_ALGO_FLOP[mode]) * 1e12 / 8e12
+        sub = {"mfma": [0, 0.0, 0.0, 0.0], "hbm": [0, 0.0, 0.0, 0.0]}
+        for name, ms, fl, by in prof.records():
+            if name in ("conv2d", "linear") and by > 0:
+                a = sub["mfma" if fl / by >= ridge else "hbm"]
+                a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
+        roof["by_launch_bound"] = {
+            "ridge_flop_per_byte": ridge,
+            "mfma_bound": {"launches_per_tile": sub["mfma"][0], "ms_per_tile": sub["mfma"][1],
+                           "achieved_TFLOPs": sub["mfma"][2] / max(sub["mfma"][1], 1e-9) / 1e9,
+                           "frac_of_peak": sub["mfma"][2] / max(sub["mfma"][1], 1e-9) / 1e9 / peak,
+                           "executed_mfma_frac": sub["mfma"][2] / max(sub["mfma"][1], 1e-9) / 1e9 * MFMA_PER_ALGO_FLOP[mode] / peak},
+            "hbm_bound": {"launches_per_tile": sub["hbm"][0], "ms_per_tile": sub["hbm"][1],
+                          "achieved_GBs": sub["hbm"][3] / max(sub["hbm"][1], 1e-9) / 1e6,
+                          "frac_of_peak": sub["hbm"][3] / max(sub["hbm"][1], 1e-9) / 1e6 / 8000.0},
+            "note": "algorithmic FLOPs / algorithmic bytes per launch, HIP-event durations of the same single-stream pass"}
         roof["other_kernels"] = [r for r in (
             _fam("token_linear", "hbm", 8000.0, "GB/s", "token_linear_all_variants"),
             _fam("win_attn_fused", "mfma", peak, "TFLOP/s", "win_attn_fused_all_variants"),

@@ -360,3 +360,5 @@ extern "C" int ff_naf_ffn(const float* y, int ldy, float* out, int ldo, long lon
   p.oscale = out_scale; p.M = M; p.ldy = ldy; p.ldo = ldo; p.eps = eps;
   return C == 64 ? launch_naf_ffn<4>(p, (hipStream_t)stream) : launch_naf_ffn<8>(p, (hipStream_t)stream);
 }
+
+#include "naf_front.inc"

@@ -91,6 +91,7 @@ def _wf(blk: dict, heads: int, d: int) -> dict:
 # measured SLOWER on MI355X (120 vs 108 us per launch: the kernel is issue / LDS bound, not bandwidth bound), so the
 # expanded quad-interleaved table stays the default; FF_REL_BIAS=1 selects the gather.
 _REL_BIAS = os.environ.get("FF_REL_BIAS", "0") == "1"
+_NAF_FRONT = os.environ.get("FF_NAF_FRONT", "1") == "1"      # NAFBlock front half (norm1 + conv1 + conv2 + gate + pool) in one launch at C = 64 / 128
 # OCAB (576 keys per window): FF_REL_OCAB=1 gathers the bias from the rotated compact table in LDS instead of streaming the expanded
 # one (3.5 MB per head).  Bit-identical, 430 MB less traffic per launch, but 314 vs 207 us on MI355X (two dependent LDS reads per score):
 # the expanded table stays the default.
@@ -499,11 +500,14 @@ class NafnetHIP:
     def block(self, x: T, k: dict) -> T:
         c = x.shape[-1]
         flash = _fast() and c in (64, 128)                                   # HR levels: the bandwidth-bound ones
-        if flash:
-            t = ops.token_linear(x, _tl(k, "c1"), gamma=k["n1"][0], beta=k["n1"][1], eps=1e-6)    # LayerNorm2d + conv1
+        if flash and _NAF_FRONT:                                             # LayerNorm2d + conv1 + conv2 + SimpleGate + pool sums: one launch
+            g, pooled = ops.naf_front(x, _tl(k, "c1"), k["n1"][0], k["n1"][1], *k["c2"])
         else:
-            t = ops.linear(ops.layernorm(x, *k["n1"], eps=1e-6), *k["c1"])
-        g, pooled = ops.dwconv3_gate_pool(t, *k["c2"])                       # conv2 + SimpleGate + SCA pool sums
+            if flash:
+                t = ops.token_linear(x, _tl(k, "c1"), gamma=k["n1"][0], beta=k["n1"][1], eps=1e-6)    # LayerNorm2d + conv1
+            else:
+                t = ops.linear(ops.layernorm(x, *k["n1"], eps=1e-6), *k["c1"])
+            g, pooled = ops.dwconv3_gate_pool(t, *k["c2"])                   # conv2 + SimpleGate + SCA pool sums
         sca = ops.vec_mlp(pooled, *k["sca"], None)                           # [1,c]
         nf = ops.gemm_mode() != "f32"                                        # the split-bf16 GEMM carries both NAFBlock fusions
         if nf:                                                               # conv3(g * sca): the scale rides on the A operand

@@ -537,6 +537,23 @@ def dwconv3_gate_pool(t: T, w_tap: T, bias: T):
     return out, pooled
 
 
+def naf_front(x: T, pk: dict, ln_g: T, ln_b: T, w_tap: T, dw_bias: T, eps: float = 1e-6):
+    """x [1,H,W,C] (C = 64 / 128) -> (SimpleGate(dw3x3(conv1(LayerNorm2d(x)))) [1,H,W,C], its per-channel mean [1,C]) in one launch;
+    pk = prep.pack_token_linear(conv1 weight [2C, C], bias), w_tap [9, 2C] tap-major depth-wise weights."""
+    xp, ldx, B, H, W, C = _nhwc(x, "naf_front.x")
+    if B != 1 or C not in (64, 128) or pk["N"] != 2 * C or pk["K"] != C or pk["kpad"] != C or tuple(w_tap.shape) != (9, 2 * C):
+        raise _lib.FFError("naf_front: expects B == 1, C in (64, 128), conv1 packed as [2C, C], [9, 2C] tap-major weights")
+    out = torch.empty((1, H, W, C), device=x.device, dtype=torch.float32)
+    pooled = torch.empty((1, C), device=x.device, dtype=torch.float32)
+    nwork = int(_L().ff_naf_front_workspace(H, W, C))
+    work = torch.empty(nwork, device=x.device, dtype=torch.float32)
+    _lib.check(_L().ff_naf_front(xp, ldx, H, W, C, ln_g.data_ptr(), ln_b.data_ptr(), float(eps), pk["w"].data_ptr(), pk["b"].data_ptr(),
+                                 w_tap.data_ptr(), dw_bias.data_ptr(), out.data_ptr(), C, pooled.data_ptr(), work.data_ptr(), nwork,
+                                 _stream()))
+    _note(2.0 * H * W * 2 * C * (C + 9), 4.0 * H * W * 2 * C)
+    return out, pooled
+
+
 def naf_ffn(y: T, pk: dict, ln_g: T, ln_b: T, out_scale: T, eps: float = 1e-6) -> T:
     """y + out_scale * conv5(SimpleGate(conv4(LayerNorm(y)))) in one launch (C = 64 / 128, bf16x3)."""
     yp, ldy, rows, C = rows_view(y, "naf_ffn.y")

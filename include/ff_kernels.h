@@ -188,6 +188,16 @@ int ff_token_linear_gated(const float* x, int ldx, const float* x2, int ldx2, co
 long long ff_dwconv3_gate_pool_workspace(int C);
 int ff_dwconv3_gate_pool(const float* in, int ldi, float* out, int ldo, int H, int W, int C, const float* w_tapmajor,
                          const float* bias, float* pooled, float* work, long long work_floats, void* stream);
+
+/* NAFBlock front half in one launch (csrc/naf_front.inc; nafnet_arch.py:88-98) for C = 64 / 128:
+ *   g = SimpleGate(dw3x3(conv1(LayerNorm2d(x)))), pooled = mean over pixels of g (SCA's average pool).
+ * x [H*W][ldx] (C channels), out [H*W][ldo] (C channels), w1_tiles = prep.pack_token_linear image of conv1 [2C, C] (bf16 hi/lo 32-row
+ * tiles), b1 [2C], dw_tapmajor [9][2C], dw_bias [2C], work >= ff_naf_front_workspace(H, W, C) floats.  Replaces ff_token_linear
+ * (LayerNorm + conv1) followed by ff_dwconv3_gate_pool: the 2C-wide tensor between them never reaches memory. */
+long long ff_naf_front_workspace(int H, int W, int C);
+int ff_naf_front(const float* x, int ldx, int H, int W, int C, const float* ln_gamma, const float* ln_beta, float eps,
+                 const void* w1_tiles, const float* b1, const float* dw_tapmajor, const float* dw_bias, float* out, int ldo,
+                 float* pooled, float* work, long long work_floats, void* stream);
 int ff_naf_ffn(const float* y, int ldy, float* out, int ldo, long long M, int C, const float* gamma_ln, const float* beta_ln,
                float eps, const void* w_tiles, const float* b4, const float* b5, const float* out_scale, void* stream);
 

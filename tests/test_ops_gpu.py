@@ -177,6 +177,37 @@ def test_gemm_tile_forms_agree_with_torch(dev, hint, M, K, N, k):
         ops.set_gemm_mode(prev)
 
 
+@pytest.mark.parametrize("C,H,W", [(64, 64, 96), (128, 40, 48), (64, 37, 53), (128, 9, 17)])
+def test_naf_front_fused(dev, C, H, W):
+    """LayerNorm2d + conv1 + depth-wise 3x3 + SimpleGate + average pool in one launch against the PyTorch fp32 chain (ragged tiles:
+    the zero padding of the depth-wise conv applies to conv1's OUTPUT, nafnet_arch.py:88-98)."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_token_linear, pack_dw
+    prev = ops.gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        x = rnd(1, C, H, W, dev=dev, seed=140, scale=1.5) + 0.2
+        g, b = rnd(C, dev=dev, seed=141) * 0.1 + 1, rnd(C, dev=dev, seed=142) * 0.1
+        w1, b1 = rnd(2 * C, C, dev=dev, seed=143, scale=1.0 / math.sqrt(C)), rnd(2 * C, dev=dev, seed=144, scale=0.1)
+        w2, b2 = rnd(2 * C, 1, 3, 3, dev=dev, seed=145, scale=0.3), rnd(2 * C, dev=dev, seed=146, scale=0.1)
+        mu = x.mean(1, keepdim=True)
+        var = (x - mu).pow(2).mean(1, keepdim=True)
+        xn = (x - mu) / (var + 1e-6).sqrt() * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+        t = F.conv2d(F.conv2d(xn, w1.view(2 * C, C, 1, 1), b1), w2, b2, padding=1, groups=2 * C)
+        ref = t[:, :C] * t[:, C:]
+        xh = x.permute(0, 2, 3, 1).contiguous()
+        got, pooled = ops.naf_front(xh, pack_token_linear(w1, b1), g, b, pack_dw(w2), b2)
+        close(got.permute(0, 3, 1, 2), ref, 2 * GEMM_TOL["bf16x3"], "naf front")
+        close(pooled, ref.mean(dim=(2, 3)), 2 * GEMM_TOL["bf16x3"], "naf front pool")
+        # and against the two-launch path it replaces
+        t2 = ops.token_linear(xh, pack_token_linear(w1, b1), gamma=g, beta=b, eps=1e-6)
+        g2, p2 = ops.dwconv3_gate_pool(t2, pack_dw(w2), b2)
+        close(got, g2, 1e-5, "naf front vs two launches")
+        close(pooled, p2, 1e-5, "naf front pool vs two launches")
+    finally:
+        ops.set_gemm_mode(prev)
+
+
 @pytest.mark.parametrize("M,K,N", [(4096, 1024, 2048), (1000, 256, 512), (333, 64, 128)])
 def test_linear_input_scale_and_simple_gate_epilogue(dev, M, K, N):
     """The two NAFBlock fusions of the split-bf16 GEMM (nafnet_arch.py:88-106): conv3(x * sca) as a scale on the A operand, and
