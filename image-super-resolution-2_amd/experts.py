@@ -500,7 +500,8 @@ class NafnetHIP:
     def block(self, x: T, k: dict) -> T:
         c = x.shape[-1]
         flash = _fast() and c in (64, 128)                                   # HR levels: the bandwidth-bound ones
-        if flash and _NAF_FRONT:                                             # LayerNorm2d + conv1 + conv2 + SimpleGate + pool sums: one launch
+        if flash and _NAF_FRONT and c == 64:                                 # LayerNorm2d + conv1 + conv2 + SimpleGate + pool sums: one launch (313 vs 381 us at
+                                                                             # 1024 x 1024; the 128-channel form fits one workgroup per CU only and ties: 222 vs 217)
             g, pooled = ops.naf_front(x, _tl(k, "c1"), k["n1"][0], k["n1"][1], *k["c2"])
         else:
             if flash:
