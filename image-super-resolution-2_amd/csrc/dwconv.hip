@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void dwconv_vec4_kernel(DwParams p) {
 // 4-row output strip, keeps the 9 tap weights in registers and slides a 3-column window down 6 input rows, so each
 // output costs 4.5 float4 loads instead of 9 and no per-tap weight loads or bounds branches.
 template <int ACT>
-__global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(DwParams p) {
+__global__ __launch_bounds__(256, 4) void dwconv3x3_strip_kernel(DwParams p) {
   const int c4n = p.C >> 2;
   const int nstrip = (p.H + 3) >> 2;
   const long long total = (long long)p.B * nstrip * p.W * c4n;
@@ -67,40 +67,44 @@ __global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(DwParams p) {
     f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : z4;
     f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pt = z4;
     if (p.ps) { ps = *reinterpret_cast<const f32x4*>(p.ps + c); pt = *reinterpret_cast<const f32x4*>(p.pt + c); }
-    f32x4 in[6][3];
+    // one input row at a time feeding up to three output rows (see dwconv3x3_ln_strip_kernel): same (ky, kx) accumulation order per
+    // output, a third fewer live registers, four waves per SIMD
+    f32x4 acc4[4] = {z4, z4, z4, z4};
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const int iy = y0 - 1 + r;
       const bool oky = (unsigned)iy < (unsigned)p.H;
+      f32x4 t[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int ix = ox - 1 + k;
         const bool ok = oky && (unsigned)ix < (unsigned)p.W;
         const f32x4 u = *reinterpret_cast<const f32x4*>(p.in + (ok ? ((long long)(b * p.H + iy) * p.W + ix) * p.ldi + c : 0));
-        in[r][k] = ok ? u : z4;
+        t[k] = ok ? u : z4;
       }
-    }
-    f32x4 mul[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = p.mulin && y0 + r < p.H;
-      mul[r] = ok ? *reinterpret_cast<const f32x4*>(p.mulin + ((long long)(b * p.H + y0 + r) * p.W + ox) * p.ldm + c) : (f32x4){1.f, 1.f, 1.f, 1.f};
+      for (int ky = 2; ky >= 0; --ky) {
+        const int o = r - ky;
+        if (o >= 0 && o < 4) {
+          acc4[o] += t[0] * w[ky * 3];
+          acc4[o] += t[1] * w[ky * 3 + 1];
+          acc4[o] += t[2] * w[ky * 3 + 2];
+        }
+      }
+      asm volatile("" : "+v"(acc4[0]), "+v"(acc4[1]), "+v"(acc4[2]), "+v"(acc4[3]) : : "memory");
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (y0 + r >= p.H) break;
-      f32x4 acc = z4;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc += in[r + ky][kx] * w[ky * 3 + kx];
-      acc = (acc + bias) * ps + pt;
+      const long long pix = (long long)(b * p.H + y0 + r) * p.W + ox;
+      const f32x4 acc = (acc4[r] + bias) * ps + pt;
+      const f32x4 m = p.mulin ? *reinterpret_cast<const f32x4*>(p.mulin + pix * p.ldm + c) : (f32x4){1.f, 1.f, 1.f, 1.f};
       f32x4 o;
 #pragma unroll
       // GELU through the 1.5e-7-accurate erf of ff_gelu_fast: the libm erff costs ~55 VALU ops with divergent branches and made
       // this HBM-bound kernel VALU-bound (66 us for 94 MB at 65 536 x 180; r2)
-      for (int e = 0; e < 4; ++e) o[e] = ff_act_c<ACT, true>(acc[e]) * mul[r][e];
-      *reinterpret_cast<f32x4*>(p.out + ((long long)(b * p.H + y0 + r) * p.W + ox) * p.ldo + c) = o;
+      for (int e = 0; e < 4; ++e) o[e] = ff_act_c<ACT, true>(acc[e]) * m[e];
+      *reinterpret_cast<f32x4*>(p.out + pix * p.ldo + c) = o;
     }
   }
 }
@@ -177,7 +181,7 @@ struct DwLnParams {
   int ldm, ldi, ldo, B, H, W, C;
 };
 
-__global__ __launch_bounds__(256) void dwconv3x3_ln_strip_kernel(DwLnParams p) {
+__global__ __launch_bounds__(256, 4) void dwconv3x3_ln_strip_kernel(DwLnParams p) {
   const int c4n = p.C >> 2;
   const int nstrip = (p.H + 3) >> 2;
   const long long total = (long long)p.B * nstrip * p.W * c4n;
@@ -193,11 +197,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_ln_strip_kernel(DwLnParams p) {
     for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f32x4*>(p.w + (long long)k * p.C + c);
     const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : z4;
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c), b4 = *reinterpret_cast<const f32x4*>(p.beta + c);
-    f32x4 in[6][3];
+    // One input row at a time (three normalised elements) feeding up to three output rows: the whole 6 x 3 window never sits in
+    // registers next to the nine taps (136 VGPRs -> under 128 = four waves per SIMD for this bandwidth-bound kernel); each output
+    // still accumulates its taps in (ky, kx) order, so the result is bit-identical to the windowed form.
+    f32x4 acc4[4] = {z4, z4, z4, z4};
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const int iy = y0 - 1 + r;
       const bool oky = (unsigned)iy < (unsigned)p.H;
+      f32x4 t[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int ix = ox - 1 + k;
@@ -205,24 +213,29 @@ __global__ __launch_bounds__(256) void dwconv3x3_ln_strip_kernel(DwLnParams p) {
         const long long tk = ok ? (long long)(b * p.H + iy) * p.W + ix : 0;
         const f32x4 u = *reinterpret_cast<const f32x4*>(p.in + tk * p.ldi + c);
         const float2 ms = *reinterpret_cast<const float2*>(p.stats + 2 * tk);
-        in[r][k] = ok ? (u - ms.x) * ms.y * g4 + b4 : z4;
+        t[k] = ok ? (u - ms.x) * ms.y * g4 + b4 : z4;
       }
-    }
-    f32x4 mul[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = p.mulin && y0 + r < p.H;
-      mul[r] = ok ? *reinterpret_cast<const f32x4*>(p.mulin + ((long long)(b * p.H + y0 + r) * p.W + ox) * p.ldm + c) : (f32x4){1.f, 1.f, 1.f, 1.f};
+      for (int ky = 2; ky >= 0; --ky) {                          // output row o = r - ky receives its tap row ky
+        const int o = r - ky;
+        if (o >= 0 && o < 4) {
+          acc4[o] += t[0] * w[ky * 3];
+          acc4[o] += t[1] * w[ky * 3 + 1];
+          acc4[o] += t[2] * w[ky * 3 + 2];
+        }
+      }
+      asm volatile("" : "+v"(acc4[0]), "+v"(acc4[1]), "+v"(acc4[2]), "+v"(acc4[3]) : : "memory");
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc4[r] += bias;
+    // the gate operand is fetched only now (window and taps are dead): 128 VGPRs = four waves per SIMD for this bandwidth-bound kernel
+    asm volatile("" : "+v"(acc4[0]), "+v"(acc4[1]), "+v"(acc4[2]), "+v"(acc4[3]) : : "memory");
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (y0 + r >= p.H) break;
-      f32x4 acc = z4;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc += in[r + ky][kx] * w[ky * 3 + kx];
-      *reinterpret_cast<f32x4*>(p.out + ((long long)(b * p.H + y0 + r) * p.W + ox) * p.ldo + c) = (acc + bias) * mul[r];
+      const long long pix = (long long)(b * p.H + y0 + r) * p.W + ox;
+      const f32x4 m = p.mulin ? *reinterpret_cast<const f32x4*>(p.mulin + pix * p.ldm + c) : (f32x4){1.f, 1.f, 1.f, 1.f};
+      *reinterpret_cast<f32x4*>(p.out + pix * p.ldo + c) = acc4[r] * m;
     }
   }
 }
