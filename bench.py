@@ -159,9 +159,9 @@ def time_mode(mode: str, sd, dev, lr, steps: int):
 
 def self_spawn(args) -> int:
     """`python bench.py --gpus N` called plainly: start N fresh ranks of this script (no GPU call has happened in this process)."""
-    from isr2_amd.parallel import spawn_ranks
-    ndev = torch.cuda.device_count()                          # counting devices does not initialise the GPU
-    if os.environ.get("FF_DIST_BACKEND", "nccl") == "nccl" and args.gpus > ndev:
+    from isr2_amd.parallel import spawn_ranks, visible_gpu_count
+    ndev = visible_gpu_count()                                # sysfs / visibility lists: the parent makes no HIP call at all
+    if os.environ.get("FF_DIST_BACKEND", "nccl") == "nccl" and 0 <= ndev < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible on this node (one rank per GPU over RCCL)", file=sys.stderr)
         return 2
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]

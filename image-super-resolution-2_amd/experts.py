@@ -485,17 +485,19 @@ class NafnetHIP:
         self.decs = [[blk(f"decoders.{l}.{b}.") for b in range(n)] for l, n in enumerate(dec)]
         self.downs = [(w.conv(f"downs.{l}"), w(f"downs.{l}.bias")) for l in range(len(enc))]
         self.ups = [w(f"ups.{l}.0.weight").reshape(w(f"ups.{l}.0.weight").shape[0], -1).contiguous() for l in range(len(dec))]
-        self._inp = {}
 
     def _padded_input(self, B: int, Hp: int, Wp: int, dev) -> T:
         """[B,Hp,Wp,3] buffer whose padding (check_image_size, nafnet_arch.py:220-225: zeros right/bottom) was zeroed ONCE when
-        the buffer was made; the resampler only ever writes the top-left H x W region, so no fill runs per forward.  Kept per
-        shape for the life of the model: a captured HIP graph may hold the address."""
-        key = (B, Hp, Wp, str(dev), ops.lane())
-        buf = self._inp.get(key)
-        if buf is None:
-            buf = self._inp[key] = torch.zeros((B, Hp, Wp, 3), device=dev, dtype=torch.float32)
-        return buf
+        the buffer was made; the resampler only ever writes the top-left H x W region, so no fill runs per forward.  Owned by the
+        graph entry being captured (its address is in the captured launches) or, for eager forwards, one buffer that is replaced
+        when the size changes (ops.persistent_zeros)."""
+        return ops.persistent_zeros(id(self), "naf_in", (B, Hp, Wp, 3), dev)
+
+    def __del__(self):
+        try:
+            ops.drop_persistent(owner=id(self))
+        except Exception:                                   # interpreter shutdown
+            pass
 
     def block(self, x: T, k: dict) -> T:
         c = x.shape[-1]

@@ -291,17 +291,18 @@ class HierFusion:
             w76 = torch.zeros(w.shape[0], 9, 76, device=w.device)
             w76[:, :, :73] = w.reshape(w.shape[0], 9, 73)
             self.st[name]["c0"] = (w76.reshape(w.shape[0], 9 * 76).contiguous(), b)
-        self._cat = {}
 
     def _cat_buf(self, h: int, w: int, dev, key: str) -> T:
-        """[1,h,w,76] concat buffer whose channels 73..75 are zero (allocated zeroed once per size; never written again).
-        One buffer per (role, size), kept for the life of the model: a HIP graph captured at one size keeps its address valid
-        when a forward at another size comes in between."""
-        k = (key, h, w, str(dev), ops.lane())
-        buf = self._cat.get(k)
-        if buf is None:
-            buf = self._cat[k] = torch.zeros((1, h, w, 76), device=dev, dtype=torch.float32)
-        return buf
+        """[1,h,w,76] concat buffer whose channels 73..75 are zero (zeroed when the buffer is made; never written again).
+        Owned by the graph entry being captured, or -- for eager forwards -- one buffer per role that is replaced on a size
+        change (ops.persistent_zeros): HBM stays bounded over a directory of differently sized images."""
+        return ops.persistent_zeros(id(self), key, (1, h, w, 76), dev)
+
+    def __del__(self):
+        try:
+            ops.drop_persistent(owner=id(self))
+        except Exception:                                   # interpreter shutdown
+            pass
 
     def _stage(self, x: T, name: str) -> T:
         k = self.st[name]

@@ -159,9 +159,13 @@ class FreqFusionHIP:
         if ent is None:
             if len(self._graphs) >= self.max_graphs:          # each graph pins its own activation pool: keep a few shapes only
                 torch.cuda.synchronize(self.dev)              # (a replay of the evicted graph may still be in flight on a lane)
-                self._graphs.pop(next(iter(self._graphs)))
+                old = next(iter(self._graphs))
+                self._graphs.pop(old)
+                from . import ops as _ops
+                _ops.drop_persistent(key=(id(self),) + old)   # the concat / padded-input buffers that graph's launches point at
             from . import ops
             ops.set_lane(lane)
+            ops.set_capture_key((id(self),) + key)
             try:
                 with torch.cuda.device(self.dev):
                     static_in = lr.clone().contiguous()
@@ -177,6 +181,7 @@ class FreqFusionHIP:
                         static_out = self.forward(static_in)
             finally:
                 ops.set_lane(0)
+                ops.set_capture_key(None)
             ent = self._graphs[key] = (graph, static_in, static_out)
         return ent
 

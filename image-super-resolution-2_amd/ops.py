@@ -135,6 +135,57 @@ def set_lane(k: int) -> None:
     _LANE = int(k)
 
 
+# Buffers that must outlive a forward because part of them is zeroed ONCE and never written again (the hierarchical fusion's
+# 76-channel concat buffers, NAFNet's zero-padded input).  Two ownership regimes:
+#   * inside model._graph_for (capture key set): the buffer belongs to THAT graph entry -- its address is baked into the captured
+#     launches -- and is dropped with it when the entry is evicted (drop_persistent);
+#   * eager forwards (no capture key): ONE buffer per (owner, role, device), replaced and re-zeroed when the size changes, so a
+#     directory of images with many distinct shapes does not accumulate a buffer per shape.
+_CAPTURE_KEY = None
+_PERSIST_GRAPH: Dict[tuple, Dict[tuple, T]] = {}
+_PERSIST_EAGER: Dict[tuple, T] = {}
+
+
+def set_capture_key(key) -> None:
+    global _CAPTURE_KEY
+    _CAPTURE_KEY = key
+
+
+def persistent_zeros(owner: int, role: str, shape, device) -> T:
+    shape = tuple(int(v) for v in shape)
+    if _CAPTURE_KEY is not None:
+        slot = _PERSIST_GRAPH.setdefault(_CAPTURE_KEY, {})
+        k = (owner, role, shape, str(device))
+        buf = slot.get(k)
+        if buf is None:
+            buf = slot[k] = torch.zeros(shape, device=device, dtype=torch.float32)
+        return buf
+    k = (owner, role, str(device))
+    buf = _PERSIST_EAGER.get(k)
+    if buf is None or tuple(buf.shape) != shape:
+        _PERSIST_EAGER.pop(k, None)                         # release the old size before the new one is allocated
+        buf = _PERSIST_EAGER[k] = torch.zeros(shape, device=device, dtype=torch.float32)
+    return buf
+
+
+def drop_persistent(key=None, owner: int = None) -> None:
+    """Release the buffers of one evicted graph entry (key), or everything an owner object holds (owner = id(obj))."""
+    if key is not None:
+        _PERSIST_GRAPH.pop(key, None)
+    if owner is not None:
+        for slot in _PERSIST_GRAPH.values():
+            for k in [k for k in slot if k[0] == owner]:
+                del slot[k]
+        for k in [k for k in _PERSIST_EAGER if k[0] == owner]:
+            del _PERSIST_EAGER[k]
+
+
+def persistent_bytes() -> int:
+    n = sum(b.numel() for b in _PERSIST_EAGER.values())
+    n += sum(b.numel() for slot in _PERSIST_GRAPH.values() for b in slot.values())
+    return 4 * n
+
+
 class PreparedWeights:
     """Kernel-side images of weight tensors (bf16 hi/lo planes, LDS tile images, interleaved bias tables), built once per weight
     and kind.  An explicit registry instead of ad-hoc attributes on the tensors: it is thread-safe, it can be enumerated (the plan

@@ -75,15 +75,48 @@ def free_port() -> int:
     return p
 
 
-def spawn_ranks(cmd: List[str], world: int, extra_env: Dict[str, str] = None, timeout: float = None) -> int:
+def visible_gpu_count() -> int:
+    """GPUs this process may use, WITHOUT any HIP / torch.cuda call (a launcher parent must stay GPU-free: its children are
+    started by fork+exec).  The visibility lists (ROCR_VISIBLE_DEVICES, HIP_VISIBLE_DEVICES, CUDA_VISIBLE_DEVICES) win when
+    set; otherwise the KFD topology is counted: a node is a GPU when its `simd_count` property is non-zero.  -1 = unknown
+    (no sysfs topology readable): the caller lets the ranks themselves fail."""
+    import os
+    counts = []
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            counts.append(len([t for t in v.split(",") if t.strip() != ""]))
+    if counts:
+        return min(counts)
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(root)
+    except OSError:
+        return -1
+    n = 0
+    for d in nodes:
+        try:
+            for line in open(os.path.join(root, d, "properties")):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            return -1
+    return n
+
+
+def spawn_ranks(cmd: List[str], world: int, extra_env: Dict[str, str] = None, timeout: float = None, poll: float = 0.2) -> int:
     """Start `world` fresh child processes of `cmd`, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
-    in their environment, as torch.distributed.run would set them), wait for all, return the worst exit code.
+    in their environment, as torch.distributed.run would set them) and return the job's exit code: 0 when every rank exits 0,
+    otherwise the FIRST non-zero code seen -- at which point the surviving ranks are ended at once (they would sit in the
+    weight broadcast or the closing all_gather until the process-group timeout, 10-30 minutes).
     The caller must not have touched the GPU: children are started with subprocess (fork+exec of a process that never
     initialised HIP), never by re-exec'ing a GPU process.  Rank 0 inherits stdout (its JSON line / progress is the job's);
     the other ranks' stdout goes to stderr so a single machine-readable line stays on stdout."""
     import os
     import subprocess
     import sys
+    import time
     port = os.environ.get("MASTER_PORT") or str(free_port())
     procs = []
     for r in range(world):
@@ -93,15 +126,27 @@ def spawn_ranks(cmd: List[str], world: int, extra_env: Dict[str, str] = None, ti
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
-    worst = 0
+    deadline = None if timeout is None else time.monotonic() + timeout
+    code = 0
     try:
-        for p in procs:
-            rc = p.wait(timeout=timeout)
-            if rc != 0:
-                worst = worst or rc
+        live = list(procs)
+        while live:
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0:
+                    code = rc
+                    print(f"spawn_ranks: rank {procs.index(p)} exited with {rc}; ending the other {len(live)} rank(s)", file=sys.stderr)
+                    return code
+            if deadline is not None and time.monotonic() > deadline:
+                raise subprocess.TimeoutExpired(cmd, timeout)
+            if live:
+                time.sleep(poll)
     finally:
-        for p in procs:                      # a rank that failed leaves its peers waiting in a collective: end exactly those PIDs
+        for p in procs:                      # exactly the PIDs started above
             if p.poll() is None:
                 p.kill()
                 p.wait()
-    return worst
+    return code

@@ -39,19 +39,26 @@ def main(argv=None) -> int:
     if args.worker or int(os.environ.get("WORLD_SIZE", "1")) > 1:
         worker(args)
         return 0
-    import torch
-    ndev = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    from .parallel import spawn_ranks, visible_gpu_count
+    ndev = visible_gpu_count()                       # sysfs / visibility lists only: no HIP call in the launcher parent
     n = args.gpus or ndev
     if n < 1:
-        print("run_sharded: no GPU visible", file=sys.stderr)
+        print("run_sharded: no GPU visible (pass --gpus N to start N ranks anyway)", file=sys.stderr)
         return 2
-    if n > ndev and os.environ.get("FF_DIST_BACKEND", "nccl") == "nccl":
+    if 0 <= ndev < n and os.environ.get("FF_DIST_BACKEND", "nccl") == "nccl":
         print(f"run_sharded: --gpus {n} but only {ndev} GPU(s) visible (one rank per GPU over RCCL)", file=sys.stderr)
+        return 2
+    # fail in the parent, before any rank exists, on what would otherwise kill rank 0 alone and leave its peers in the broadcast
+    if not os.path.isdir(args.input):
+        print(f"run_sharded: --input {args.input!r} is not a directory", file=sys.stderr)
+        return 2
+    if not os.path.isfile(args.model_dir) and os.environ.get("FF_ALLOW_SYNTH", "0") != "1":
+        print(f"run_sharded: fusion checkpoint {os.path.abspath(args.model_dir)!r} not found "
+              "(--model_dir is a FILE path, relative to the current directory; FF_ALLOW_SYNTH=1 runs on seeded synthetic weights)", file=sys.stderr)
         return 2
     if n == 1:
         worker(args)
         return 0
-    from .parallel import spawn_ranks
     cmd = [sys.executable, "-m", "isr2_amd.run_sharded", "--worker", "--gpus", str(n), "--input", args.input, "--output", args.output,
            "--model_dir", args.model_dir]
     env = {"PYTHONPATH": ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")}

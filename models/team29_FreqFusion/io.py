@@ -238,7 +238,11 @@ def _ensure_process_group(rank: int, world: int, device):
     if dist.is_initialized():
         return False
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29529")
+    if "MASTER_PORT" not in os.environ:
+        # every launcher this build ships (torch.distributed.run, isr2_amd.run_sharded, bench.py) hands the ranks ONE port
+        # of the job; ranks cannot agree on a free one by themselves, and a fixed default would make two jobs on a node collide
+        raise RuntimeError("[team29_FreqFusion] WORLD_SIZE > 1 but MASTER_PORT is not set: start the ranks with "
+                           "torch.distributed.run or `python -m isr2_amd.run_sharded` (which picks a free port per job)")
     backend = os.environ.get("FF_DIST_BACKEND", "nccl")
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))

@@ -63,7 +63,13 @@ def evaluate(sr_dir, hr_dir, device, crop_border=4):
         ps.append(p_)
         ss.append(s_)
     if ps:
-        print(f"PSNR-Y {sum(ps) / len(ps):.4f} dB, SSIM-Y {sum(ss) / len(ss):.6f} over {len(ps)} images (crop {crop_border})")
+        # an SR image identical to its ground truth has infinite PSNR: left out of the mean, as the reference's batch evaluator
+        # does (src/utils/metrics.py:275-283), and counted
+        import math
+        finite = [v for v in ps if math.isfinite(v)]
+        mean_p = sum(finite) / len(finite) if finite else float("inf")
+        skipped = f", {len(ps) - len(finite)} identical image(s) left out of the PSNR mean" if len(finite) != len(ps) else ""
+        print(f"PSNR-Y {mean_p:.4f} dB, SSIM-Y {sum(ss) / len(ss):.6f} over {len(ps)} images (crop {crop_border}){skipped}")
 
 
 def main(args):

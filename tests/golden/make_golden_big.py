@@ -3,6 +3,8 @@
     python tests/golden/make_golden_big.py tile256     # one 256x256 LR tile (bench.py's rank-0 tile), ~3 min
     python tests/golden/make_golden_big.py config3     # BASELINE config 3: reference io._tiled_forward(model, lr, 256, 32)
                                                        #   on one 510x339 1/f image (6 tiles), ~15-20 min
+    python tests/golden/make_golden_big.py whole510    # the WHOLE-IMAGE branch (io.py:219-221) on the same 510x339 image: one
+                                                       #   model(lr) call, 172 890 tokens, ~8-10 min (+ the oracle for its pinning)
     python tests/golden/make_golden_big.py b2          # a B=2 48x48 batch through the reference (batched-forward parity)
     python tests/golden/make_golden_big.py hooks48     # the cached-expert features of forward_all_with_hooks
     python tests/golden/make_golden_big.py precomp48   # the cached-mode forward (forward_with_precomputed, SURVEY 8f rank 1's forward
@@ -113,6 +115,37 @@ def config3(model, sd):
     return {"reference_seconds_8_threads": dt, "shape": list(out.shape)}
 
 
+def whole510(model, sd):
+    """The reference's first choice for every image is ONE forward over the whole image (models/team29_FreqFusion/io.py:219-221);
+    config3() above pins only the tiled fallback.  Same 510x339 1/f image (seed 31): reflect pad to 512x352 inside the experts,
+    510/339-point FFT bands, channel attention over 172 890 tokens."""
+    h, w = 339, 510
+    lr = make_input("natural", h, w, 31)
+    t0 = time.time()
+    with torch.no_grad():
+        out = model(lr)
+    dt = time.time() - t0
+    print(f"reference model(lr) on the whole 510x339 image: {dt:.1f} s", flush=True)
+    corners = [(0, 0), (300, 880), (332, 1000), (600, 1100), (1292, 1976), (1000, 1500), (340, 20), (980, 940)]
+    blob = {"lr": lr.numpy(), "crop_corners": np.array(corners, dtype=np.int64), "crops": crops_of(out, corners)}
+    i, v = big_samples("whole510", out)
+    blob["big/idx"], blob["big/val"] = i, v
+    f = out.reshape(-1).numpy().astype(np.float64)
+    blob["stats"] = np.array([f.mean(), np.abs(f).mean(), np.sqrt((f ** 2).sum())])
+    blob["shape"] = np.array(out.shape, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "whole510_339.npz"), **blob)
+    print("wrote whole510_339.npz", flush=True)
+    rep = {"reference_seconds_8_threads": dt, "shape": list(out.shape)}
+    if os.environ.get("FF_WHOLE510_ORACLE", "1") == "1":
+        t0 = time.time()
+        oout = O.forward(sd, lr)
+        rep["oracle_seconds_8_threads"] = time.time() - t0
+        rep["oracle_vs_reference_max_abs"] = float((oout - out).abs().max())
+        rep["oracle_vs_reference_psnr"] = O.psnr(oout, out)
+        print("oracle-vs-reference on the whole 510x339 image:", rep["oracle_vs_reference_max_abs"], rep["oracle_vs_reference_psnr"], flush=True)
+    return rep
+
+
 def b2(model, sd):
     lr = torch.cat([make_input("natural", 48, 48, 41), make_input("uniform", 48, 48, 42)], 0)
     with torch.no_grad():
@@ -184,7 +217,7 @@ def main():
     rp = os.path.join(HERE, "big_pinning_report.json")
     report = json.load(open(rp)) if os.path.exists(rp) else {}
     for wname in what:
-        report[wname] = {"tile256": tile256, "config3": config3, "b2": b2, "hooks48": hooks48, "precomp48": precomp48}[wname](model, sd)
+        report[wname] = {"tile256": tile256, "config3": config3, "whole510": whole510, "b2": b2, "hooks48": hooks48, "precomp48": precomp48}[wname](model, sd)
         json.dump(report, open(rp, "w"), indent=1)
 
 

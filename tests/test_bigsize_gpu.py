@@ -164,3 +164,51 @@ def test_batch2_matches_reference_and_single(model):
     assert (out.cpu() - ref).abs().max().item() < tol
     one = torch.cat([model(lr[0:1]), model(lr[1:2])], 0)
     assert torch.equal(out, one), "batched forward differs from two single forwards"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Plain-bf16 contraction mode (FF_GEMM=bf16, BASELINE configs[1] names bf16): one MFMA term instead of three.  It is not the
+# headline mode, but it is a product mode, so it carries its own bar: PSNR against the REFERENCE's output
+# >= 60 dB (a 30 dB PSNR-vs-ground-truth then moves by < 0.005 dB) and every tap within BF16_TAP_TOL of the reference.
+BF16_BAR = (3e-2, 60.0)
+
+
+@pytest.fixture(scope="module")
+def model_bf16(synth_sd):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from isr2_amd import ops
+    from isr2_amd.model import FreqFusionHIP
+    old = ops.gemm_mode()
+    ops.set_gemm_mode("bf16")
+    m = FreqFusionHIP(synth_sd, "cuda:0")
+    m.mode = "bf16"
+    yield m
+    ops.set_gemm_mode(old)
+
+
+@pytest.mark.parametrize("case", ["c48_u8", "c42x52_nat", "t256_nat"])
+def test_plain_bf16_mode_against_reference_goldens(model_bf16, case):
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    lr = torch.from_numpy(g["lr"]).cuda()
+    taps = {}
+    out = model_bf16(lr, taps)
+    taps["final"] = out
+    tol, min_psnr = BF16_BAR
+    worst = {}
+    for n in sorted({k.split("/")[1] for k in g.files if k.startswith("tap/")}):
+        if n == "fusion.gates" or n not in taps:
+            continue                                                    # hard threshold: covered by the final image's bar
+        t = _as_ref_layout(taps[n], g[f"tap/{n}/shape"])
+        ref = torch.from_numpy(g[f"tap/{n}/val"])
+        got = t.reshape(-1)[torch.from_numpy(g[f"tap/{n}/idx"])]
+        worst[n] = (got - ref).abs().max().item() / max(1.0, float(ref.abs().max()))
+    print(case, "bf16 worst taps:", sorted(worst.items(), key=lambda kv: -kv[1])[:8])
+    bad = {k: v for k, v in worst.items() if not v < tol}
+    assert not bad, bad
+    if f"full/final" in g.files:
+        psnr = _psnr_from_samples(out.cpu().reshape(-1), torch.from_numpy(g["full/final"]).reshape(-1))
+    else:
+        psnr = _psnr_from_samples(out.cpu().reshape(-1)[torch.from_numpy(g["big/final/idx"])], torch.from_numpy(g["big/final/val"]))
+    print(case, "bf16 PSNR(hip, reference) =", psnr)
+    assert psnr >= min_psnr

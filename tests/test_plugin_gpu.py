@@ -250,6 +250,34 @@ def test_graphed_forward_is_bit_exact_and_survives_other_sizes(dev, hip_model):
     assert torch.equal(hip_model(a2), ga3)
 
 
+def test_persistent_buffers_stay_bounded_over_many_shapes(dev, hip_model):
+    """the zero-padded concat / input buffers that outlive a forward are owned by the graph entry that captured
+    them (dropped on eviction) or, for eager forwards, exist once per role (replaced on a size change) -- a directory of
+    differently sized images must not accumulate one set per shape."""
+    from isr2_amd import ops
+    rng = np.random.default_rng(9)
+    shapes = [(24 + 4 * i, 20 + 8 * i) for i in range(hip_model.max_graphs + 4)]
+    owners = {id(hip_model.fusion.hier), id(hip_model.nafnet)}
+    for h, w in shapes:                                                        # eager forwards: one set of buffers, whatever came before
+        lr = torch.from_numpy(rng.random((1, 3, h, w), dtype=np.float32)).to(dev)
+        ref = hip_model(lr).clone()
+        mine = {k: tuple(b.shape) for k, b in ops._PERSIST_EAGER.items() if k[0] in owners}
+        assert len(mine) == 3, mine                                            # in2, in3, NAFNet's padded input -- not 3 per shape seen
+        assert sorted(mine.values())[-1] == (1, 4 * h, 4 * w, 76), mine
+        assert torch.equal(hip_model(lr), ref)
+    hmax, wmax = max(s[0] for s in shapes), max(s[1] for s in shapes)
+    one_set = 4 * (76 * (16 * hmax * wmax + 4 * hmax * wmax) + 3 * (4 * hmax + 16) * (4 * wmax + 16))
+    base = ops.persistent_bytes()
+    for h, w in shapes:                                                        # graphed: at most max_graphs sets are alive
+        lr = torch.from_numpy(rng.random((1, 3, h, w), dtype=np.float32)).to(dev)
+        out = hip_model.graphed(lr).clone()
+        assert torch.equal(out, hip_model(lr))
+        assert len(hip_model._graphs) <= hip_model.max_graphs
+        assert ops.persistent_bytes() <= base + (hip_model.max_graphs + 1) * one_set
+    n_graph_slots = sum(1 for k in ops._PERSIST_GRAPH if k[0] == id(hip_model))
+    assert n_graph_slots <= hip_model.max_graphs
+
+
 def test_two_lane_tile_pipeline_is_bit_exact(dev, hip_model, monkeypatch):
     """model.graphed_async / io._tiled_forward with two tiles in flight (two captured graphs on two lane streams, lane-keyed
     persistent buffers): the same bits as one tile at a time, on an image with full, right-edge, bottom-edge and corner tiles."""
