@@ -74,9 +74,9 @@ extern "C" int ff_ew_fma(float* out, int ldo, const float* a, int lda, const flo
 }
 
 // unary ops and their derivative forms.  op < 16: out = f(x) ; op >= 16: out = g * f'(x) (or from the output y where noted)
-enum { U_GELU = 0, U_RELU = 1, U_SIGMOID = 2, U_SOFTPLUS = 3, U_ABS = 4, U_CLAMP01 = 5, U_SCALE = 6, U_DIV_EPS = 7, U_CLAMP_MIN = 8,
+enum { U_GELU = 0, U_RELU = 1, U_SIGMOID = 2, U_SOFTPLUS = 3, U_ABS = 4, U_CLAMP01 = 5, U_SCALE = 6, U_DIV_EPS = 7, U_CLAMP_MIN = 8, U_EXP = 9,
        U_GELU_BWD = 16, U_RELU_BWD = 17, U_SIGMOID_BWD_Y = 18, U_SOFTPLUS_BWD = 19, U_ABS_BWD = 20, U_CLAMP01_BWD = 21,
-       U_RECIP_BWD = 22, U_CLAMP_MIN_BWD = 23 };
+       U_RECIP_BWD = 22, U_CLAMP_MIN_BWD = 23, U_EXP_BWD_Y = 24 };
 
 __device__ __forceinline__ float ew_unary_apply(int op, float x, float g, float p0) {
   switch (op) {
@@ -89,6 +89,7 @@ __device__ __forceinline__ float ew_unary_apply(int op, float x, float g, float 
     case U_SCALE: return x * p0;
     case U_DIV_EPS: return 1.0f / (x + p0);                                      // 1 / (x + eps)
     case U_CLAMP_MIN: return fmaxf(x, p0);
+    case U_EXP: return expf(x);
     case U_GELU_BWD: {                                                            // d/dx [x Phi(x)] = Phi(x) + x phi(x)
       const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
       const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
@@ -101,6 +102,7 @@ __device__ __forceinline__ float ew_unary_apply(int op, float x, float g, float 
     case U_CLAMP01_BWD: return (x >= 0.f && x <= 1.f) ? g : 0.f;                  // torch.clamp: bounds inclusive
     case U_RECIP_BWD: return -g * x * x;                                          // x = the reciprocal y = 1/(u+eps): dy/du = -y^2
     case U_CLAMP_MIN_BWD: return x >= p0 ? g : 0.f;
+    case U_EXP_BWD_Y: return g * x;                                               // x = exp output
     default: return x;
   }
 }
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void ew_unary_kernel(int op, const float* __re
 extern "C" int ff_ew_unary(int op, const float* x, int ldx, const float* g, int ldg, float* out, int ldo, long long rows, int C,
                            float p0, void* stream) {
   FF_CHECK_ARG(x && out && rows > 0 && C > 0 && ldx >= C && ldo >= C, "ff_ew_unary: bad args");
-  FF_CHECK_ARG((op >= 0 && op <= 8) || (op >= 16 && op <= 23), "ff_ew_unary: unknown op %d", op);
+  FF_CHECK_ARG((op >= 0 && op <= 9) || (op >= 16 && op <= 24), "ff_ew_unary: unknown op %d", op);
   FF_CHECK_ARG(op < 16 || (g && ldg >= C), "ff_ew_unary: derivative forms need the incoming gradient");
   long long nb = (rows * C + 255) / 256;
   if (nb > 16384) nb = 16384;

@@ -336,9 +336,9 @@ int ff_ssim_mean(const float* a, const float* b, int C, int H, int W, int crop, 
 int ff_ew_fma(float* out, int ldo, const float* a, int lda, const float* b, int ldb, int b_kind, const float* c, int ldc, int c_kind,
               float c_scale, long long rows, int C, long long rows_per_group, int clamp01, void* stream);
 /* out = f(x) for op < 16, out = g * f'(x) for op >= 16:
- *   0 GELU (erf) 1 ReLU 2 sigmoid 3 softplus 4 abs 5 clamp01 6 x*p0 7 1/(x+p0) 8 max(x,p0)
+ *   0 GELU (erf) 1 ReLU 2 sigmoid 3 softplus 4 abs 5 clamp01 6 x*p0 7 1/(x+p0) 8 max(x,p0) 9 exp
  *   16 GELU' 17 ReLU' 18 sigmoid' from the OUTPUT y 19 softplus' 20 abs' (sgn, 0 at 0) 21 clamp01' (bounds inclusive, as torch.clamp)
- *   22 d(1/(u+eps)) from the output y: -g y^2   23 clamp_min' (x >= p0) */
+ *   22 d(1/(u+eps)) from the output y: -g y^2   23 clamp_min' (x >= p0)   24 exp' from the output y */
 int ff_ew_unary(int op, const float* x, int ldx, const float* g, int ldg, float* out, int ldo, long long rows, int C, float p0,
                 void* stream);
 /* out[g][c] = scale * sum_{r in group g} x[r][c] * (y[r][c] | y[r*ldy] | 1): bias / BatchNorm / per-channel-scale gradients.

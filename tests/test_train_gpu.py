@@ -1,0 +1,171 @@
+"""The fusion-only training step (isr2_amd/train.py, SURVEY 8f rank 1 / BASELINE config 5) against fixtures produced by the
+IMPORTED reference (tests/golden/make_golden_train.py: train-mode forward_with_precomputed -> clamp -> L1 -> backward ->
+clip_grad_norm_(1.0) -> AdamW -> EMA, dropout 0 so that the result does not depend on an RNG stream).
+
+Bars: train-mode forward output, every BatchNorm running statistic, every gradient within 1e-4 (f32) /
+5e-4 (bf16x3) of the reference -- measured per tensor relative to max(|ref|) of that tensor with a floor of 1e-3 of the largest
+gradient tensor's maximum (tiny gradients are sums that cancel to ~1e-7: their last digits are rounding in the reference too) --
+and the parameters / EMA shadow after 3 optimizer steps."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+sys.path.insert(0, GOLD)
+BARS = {"f32": 1e-4, "bf16x3": 5e-4}
+# After n AdamW steps every value has moved by about n * lr whatever its gradient's size (the update is m / sqrt(v)): an element whose
+# gradient is ~0 takes its direction from the gradient's last bits, so the bar is a fraction of the total update n * lr, not of the
+# value (measured: 0.012 in f32, 0.075 in bf16x3 at B = 4, 32 x 32).
+PARAM_BARS = {"f32": 0.05, "bf16x3": 0.15}
+
+
+def _load(case):
+    from train_inputs import make_train_batch
+    g = np.load(os.path.join(GOLD, case))
+    meta = json.loads(str(g["meta"]))
+    d = {k: torch.from_numpy(v) for k, v in make_train_batch(meta["input_seed"], meta["B"], meta["h"], meta["w"]).items()}
+    outs = {k: d["out_" + k] for k in ("hat", "dat", "nafnet")}
+    feats = {k: d["feat_" + k] for k in ("hat", "dat", "nafnet")}
+    return g, meta, d, outs, feats
+
+
+def _cmp(g, prefix, name, t):
+    """max |t - ref| over the stored samples (or the whole tensor) and max |ref|."""
+    f = t.detach().float().reshape(-1).cpu().numpy()
+    if f"{prefix}/{name}/full" in g.files:
+        ref = g[f"{prefix}/{name}/full"]
+        got = f
+    else:
+        ref = g[f"{prefix}/{name}/val"]
+        got = f[g[f"{prefix}/{name}/idx"]]
+    l2 = float(np.sqrt((f.astype(np.float64) ** 2).sum()))
+    return float(np.abs(got - ref).max()), float(np.abs(ref).max()), l2, float(g[f"{prefix}/{name}/l2"])
+
+
+@pytest.fixture(scope="module", params=["f32", "bf16x3"])
+def mode(request):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from isr2_amd import ops
+    old = ops.gemm_mode()
+    ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode(old)
+
+
+@pytest.mark.parametrize("case", ["train_b2_16.npz", "train_b4_32.npz"])
+def test_training_step_against_reference(mode, case):
+    if not os.path.exists(os.path.join(GOLD, case)):
+        pytest.skip(case + " not generated")
+    from isr2_amd.train import FusionTrainer
+    from isr2_amd.weights import synth_state_dict
+    from isr2_amd import ops
+    g, meta, d, outs, feats = _load(case)
+    tol = BARS[mode]
+    sd = synth_state_dict(meta["weight_seed"], parts=("fusion", "collab"))
+    hp = dict(meta["hp"])
+    hp["betas"] = tuple(hp["betas"])
+    tr = FusionTrainer(sd, "cuda:0", hp=hp, dropout=0.0)
+    nograd = set(json.loads(str(g["nograd"])))
+    assert not (set(tr.names) & nograd), sorted(set(tr.names) & nograd)[:5]
+    ref_names = {k.split("/", 1)[1].rsplit("/", 1)[0] for k in g.files if k.startswith("grad/")}
+    assert set(tr.names) == ref_names, (sorted(ref_names - set(tr.names))[:5], sorted(set(tr.names) - ref_names)[:5])
+
+    # ---- step 1: forward, loss, BatchNorm statistics, gradients
+    sr, loss = tr.forward_backward(d["lr"], d["hr"], outs, feats)
+    sr_nchw = ops.nhwc_to_nchw(sr).cpu()
+    if g["sr"].size:
+        dsr = float((sr_nchw - torch.from_numpy(g["sr"])).abs().max())
+    else:
+        dsr = float((sr_nchw.reshape(-1)[torch.from_numpy(g["sr/idx"])] - torch.from_numpy(g["sr/val"])).abs().max())
+    print(case, mode, "train-mode forward max|d| =", dsr, " loss", float(loss), "ref", float(g["losses"][0]))
+    assert dsr < tol
+    assert abs(float(loss) - float(g["losses"][0])) < tol * 0.1
+    worst_bn = 0.0
+    for k, v in tr.buffers.items():
+        ref = g["bn/" + k]
+        worst_bn = max(worst_bn, float(np.abs(v.cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max())))
+    for k, n in tr.nbt.items():
+        assert n == int(g["bn/" + k]), (k, n, int(g["bn/" + k]))
+    print(case, mode, "BatchNorm running statistics worst rel. deviation =", worst_bn)
+    assert worst_bn < tol
+    grads = tr.grads()
+    gmax = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("grad/") and k.endswith(("/full", "/val")))
+    floor = 1e-3 * gmax
+    worst = {}
+    for k in tr.names:
+        dmax, rmax, l2, l2ref = _cmp(g, "grad", k, grads[k])
+        worst[k] = dmax / max(rmax, floor)
+        assert abs(l2 - l2ref) <= 20 * tol * max(l2ref, floor), (k, l2, l2ref)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
+    print(case, mode, f"{len(worst)} gradient tensors; worst relative deviations:", top)
+    bad = {k: v for k, v in worst.items() if not v < tol}
+    assert not bad, bad
+    tr.optimizer_step()
+    gn = tr.grad_norm()
+    assert abs(gn - float(g["grad_norms"][0])) < 10 * tol * float(g["grad_norms"][0]), (gn, float(g["grad_norms"][0]))
+
+    # ---- steps 2..n: losses, then parameters and EMA shadow
+    steps = meta["steps"]
+    for s in range(1, steps):
+        loss = tr.step(d["lr"], d["hr"], outs, feats)
+        assert abs(float(loss) - float(g["losses"][s])) < tol, (s, float(loss), float(g["losses"][s]))
+    psd, esd = tr.state_dict(), tr.ema_shadow()
+    wp, we = {}, {}
+    for k in tr.names:
+        dmax, rmax, *_ = _cmp(g, f"param{steps}", k, psd[k])
+        wp[k] = dmax / max(1.0, rmax)
+        dmax, rmax, *_ = _cmp(g, f"ema{steps}", k, esd[k])
+        we[k] = dmax / max(1.0, rmax)
+    # AdamW moves every value by ~lr per step whatever the gradient's size: a deviation must stay far below that step
+    step_scale = steps * hp["lr"]
+    print(case, mode, "after", steps, "steps: worst param dev", max(wp.values()), "(", max(wp.values()) / step_scale, "of the total update ); worst EMA dev", max(we.values()))
+    assert max(wp.values()) < PARAM_BARS[mode] * step_scale, sorted(wp.items(), key=lambda kv: -kv[1])[:5]
+    assert max(we.values()) < PARAM_BARS[mode] * step_scale * (1 - hp["ema_decay"]) * steps + 1e-6   # + a few ulp of the O(1) values
+    for k, v in tr.buffers.items():
+        ref = g[f"bn{steps}/" + k]
+        assert float(np.abs(v.cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max())) < tol, k
+
+
+def test_step_is_bit_reproducible_and_dropout_changes_it(mode):
+    from isr2_amd.train import FusionTrainer
+    from isr2_amd.weights import synth_state_dict
+    g, meta, d, outs, feats = _load("train_b2_16.npz")
+    sd = synth_state_dict(meta["weight_seed"], parts=("fusion", "collab"))
+
+    def run(dropout, seed):
+        tr = FusionTrainer(sd, "cuda:0", dropout=dropout, seed=seed)
+        tr.step(d["lr"], d["hr"], outs, feats)
+        tr.step(d["lr"], d["hr"], outs, feats)
+        return tr.P.clone(), tr.EMA.clone(), float(tr.loss)
+    a, b = run(0.1, 7), run(0.1, 7)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]          # fixed-order reductions, counter-based masks
+    c = run(0.1, 8)
+    assert not torch.equal(a[0], c[0])
+    e = run(0.0, 7)
+    assert not torch.equal(a[0], e[0])
+
+
+def test_trainer_refuses_cpu_and_bad_shapes():
+    from isr2_amd.train import FusionTrainer
+    from isr2_amd.weights import synth_state_dict
+    from isr2_amd.lib import FFError
+    sd = synth_state_dict(1234, parts=("fusion", "collab"))
+    with pytest.raises(FFError):
+        FusionTrainer(sd, "cpu")
+    with pytest.raises(FFError):
+        FusionTrainer(synth_state_dict(1234, parts=("fusion",)), "cuda:0")               # no collaborative.* weights
+    tr = FusionTrainer(sd, "cuda:0")
+    lr = torch.rand(1, 3, 16, 16)
+    good = {k: torch.rand(1, 3, 64, 64) for k in ("hat", "dat", "nafnet")}
+    feats = {"hat": torch.randn(1, 180, 16, 16), "dat": torch.randn(1, 180, 16, 16), "nafnet": torch.randn(1, 64, 16, 16)}
+    with pytest.raises(FFError):
+        tr.step(lr, torch.rand(1, 3, 32, 32), good, feats)
+    with pytest.raises(FFError):
+        tr.step(lr, torch.rand(1, 3, 64, 64), dict(good, dat=torch.rand(1, 3, 60, 64)), feats)
