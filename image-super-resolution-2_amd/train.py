@@ -73,7 +73,11 @@ def trainable_names(sd: Dict[str, T]) -> List[str]:
 
 
 class FusionTrainer:
-    def __init__(self, state_dict: Dict[str, T], device="cuda:0", hp: Optional[dict] = None, dropout: float = 0.1, seed: int = 0):
+    def __init__(self, state_dict: Dict[str, T], device="cuda:0", hp: Optional[dict] = None, dropout: float = 0.1, seed: int = 0,
+                 gemm: Optional[str] = "f32"):
+        """gemm: contraction mode of the step's convolutions / linear layers -- "f32" (exact fp32 MFMA, the default: the reference
+        trains in fp32, configs/train_config.yaml:100-101, and the step is not GEMM-bound: 90 vs 85 ms), "bf16x3", or None = whatever
+        ops.gemm_mode() says (the weight gradients are exact fp32 MFMA in every mode)."""
         dev = torch.device(device)
         if dev.type != "cuda" or not torch.cuda.is_available():
             raise _lib.FFError("FusionTrainer needs an MI355X (torch device 'cuda'); there is no CPU fallback")
@@ -81,10 +85,13 @@ class FusionTrainer:
         if "collaborative.norm1.weight" not in state_dict:
             raise _lib.FFError("FusionTrainer: the state dict holds no collaborative.* weights (cached-mode training needs them)")
         self.dev, self.hp, self.dropout, self.seed = dev, dict(HP, **(hp or {})), float(dropout), int(seed)
+        self.gemm = gemm
         self.step_count = 0
+        self.key_order = list(state_dict.keys())
         self.names = trainable_names(state_dict)
         self.ref_shape = {k: tuple(state_dict[k].shape) for k in self.names}
-        self.other = OrderedDict((k, v.clone()) for k, v in state_dict.items() if k not in self.ref_shape and not _is_buffer(k))   # dead / fixed tensors
+        self.other = OrderedDict((k, v.clone()) for k, v in state_dict.items()                                    # dead / fixed tensors
+                                 if k not in self.ref_shape and not _is_buffer(k) and not k.startswith("expert_ensemble."))
         offs, n = {}, 0
         for k in self.names:
             offs[k] = n
@@ -385,6 +392,15 @@ class FusionTrainer:
         outs = {k: self._to_dev(v) for k, v in outs.items()}
         feats = {k: self._to_dev(v) for k, v in feats.items()}
         self._check_batch(lr, hr, outs, feats)
+        old_mode = ops.gemm_mode()
+        if self.gemm is not None:
+            ops.set_gemm_mode(self.gemm)
+        try:
+            return self._forward_backward(lr, hr, outs, feats)
+        finally:
+            ops.set_gemm_mode(old_mode)
+
+    def _forward_backward(self, lr, hr, outs, feats):
         with torch.cuda.device(self.dev):
             self.G.zero_()
             with ag.Tape() as tape:
@@ -455,3 +471,158 @@ class FusionTrainer:
 
     def grad_norm(self) -> float:
         return float(torch.sqrt(self.sqnorm).cpu())
+
+
+# ======================================================================================================================
+# Checkpoint contract of the training side (reference src/utils/checkpoint_manager.py:81-165 save, :185-239 load, train.py:961-966)
+def is_parameter_key(k: str) -> bool:
+    """Parameters (as opposed to registered buffers) among the keys of the reference model's state dict."""
+    if k.endswith(BN_SUFFIX):
+        return False
+    return not k.startswith(("multi_domain_freq.dct.dct_basis", "multi_domain_freq.dct.low_mask", "multi_domain_freq.dct.mid_mask",
+                             "multi_domain_freq.dct.high_mask", "multi_domain_freq.dwt.lo_", "multi_domain_freq.dwt.hi_", "edge_refine.gaussian.kernel"))
+
+
+def build_checkpoint(model_sd: Dict[str, T], exp_avg: Dict[str, T], exp_avg_sq: Dict[str, T], ema_shadow: Dict[str, T], step: int, hp: dict,
+                     epoch: int, metrics: Optional[dict] = None, lr_now: Optional[float] = None, scheduler_state: Optional[dict] = None,
+                     stage: Optional[int] = None) -> dict:
+    """The dict CheckpointManager.save_checkpoint writes, from host tensors in the reference's layouts:
+        {epoch, model_state_dict, optimizer_state_dict, [scheduler_state_dict], ema_state_dict{shadow, decay}, metrics, timestamp}
+    `model_sd` must be a COMPLETE state dict of the (cached-mode) reference model in its own key order -- the optimizer state is
+    indexed by the position of each parameter in model.parameters(), which is the order of the parameter keys of that dict.
+    Parameters without gradient (exp_avg has no entry: freq_router.*, expert_weights, band_importance) get no optimizer state, exactly as
+    torch.optim.AdamW leaves them."""
+    from datetime import datetime
+    pkeys = [k for k in model_sd if is_parameter_key(k) and not k.startswith("expert_ensemble.")]
+    state = {}
+    for i, k in enumerate(pkeys):
+        if k in exp_avg:
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": exp_avg[k].clone(), "exp_avg_sq": exp_avg_sq[k].clone()}
+    # the param_group of THIS torch version's AdamW (so that optimizer.load_state_dict finds every key it expects)
+    probe = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=hp["lr"], betas=tuple(hp["betas"]), eps=hp["eps"], weight_decay=hp["weight_decay"])
+    group = dict(probe.state_dict()["param_groups"][0])
+    group["params"] = list(range(len(pkeys)))
+    group["lr"] = float(hp["lr"] if lr_now is None else lr_now)
+    group.setdefault("initial_lr", float(hp["lr"]))                  # what CosineAnnealingWarmRestarts adds to the groups (train.py:897)
+    ck = {"epoch": int(epoch), "model_state_dict": OrderedDict((k, v.clone()) for k, v in model_sd.items()),
+          "optimizer_state_dict": {"state": state, "param_groups": [group]}, "metrics": dict(metrics or {}),
+          "timestamp": datetime.now().isoformat(),
+          "ema_state_dict": {"shadow": {k: v.clone() for k, v in ema_shadow.items()}, "decay": float(hp["ema_decay"])}}
+    if scheduler_state is not None:
+        ck["scheduler_state_dict"] = dict(scheduler_state)
+    if stage is not None:
+        ck["stage"] = stage
+    return ck
+
+
+def _save_atomic(ck: dict, path: str):
+    tmp = os.path.splitext(path)[0] + ".tmp"
+    torch.save(ck, tmp)
+    os.replace(tmp, path)                                             # checkpoint_manager.py:136-139: temp file, then rename
+
+
+def _trainer_save(self, path: str, epoch: int, metrics: Optional[dict] = None, lr_now: Optional[float] = None,
+                  scheduler_state: Optional[dict] = None) -> str:
+    """Write a checkpoint in the reference's layout (loadable by its CheckpointManager.load_checkpoint when this trainer was built
+    from a complete reference state dict; a later FusionTrainer.load_checkpoint resumes bit-exactly either way)."""
+    ck = build_checkpoint(self.state_dict_in_order(), self._export(self.M), self._export(self.V), self.ema_shadow(), self.step_count, self.hp,
+                          epoch, metrics, lr_now, scheduler_state)
+    ck["ff_trainer"] = {"seed": self.seed, "dropout": self.dropout, "step_count": self.step_count}
+    _save_atomic(ck, path)
+    return path
+
+
+def _state_dict_in_order(self) -> "OrderedDict[str, T]":
+    """state_dict() in the key order of the state dict the trainer was built from (the reference model's own order when that was a
+    reference state dict): parameter positions index the optimizer state."""
+    sd = self.state_dict()
+    out = OrderedDict((k, sd[k]) for k in self.key_order if k in sd)
+    for k, v in sd.items():
+        out.setdefault(k, v)
+    return out
+
+
+def _trainer_load(self, path_or_ckpt, load_optimizer: bool = True):
+    """Resume from a checkpoint of the reference's layout (its own CheckpointManager files, or ones written by save_checkpoint):
+    model_state_dict (module. / model. prefixes stripped, as the plugin does), optimizer state by parameter position, EMA shadow."""
+    ck = torch.load(path_or_ckpt, map_location="cpu", weights_only=True) if isinstance(path_or_ckpt, (str, os.PathLike)) else path_or_ckpt
+    msd = OrderedDict()
+    for k, v in ck["model_state_dict"].items():
+        for pre in ("module.", "model."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        msd[k] = v
+    missing = [k for k in self.names if k not in msd]
+    if missing:
+        raise _lib.FFError(f"checkpoint lacks {len(missing)} trainable tensors, e.g. {missing[:3]}")
+
+    def put(flat, d, names):
+        for k in names:
+            if tuple(d[k].shape) != self.ref_shape[k]:
+                raise _lib.FFError(f"checkpoint tensor {k}: shape {tuple(d[k].shape)} != {self.ref_shape[k]}")
+            flat[self.offs[k]:self.offs[k] + d[k].numel()].copy_(to_native(k, d[k].float()).reshape(-1))
+    put(self.P, msd, self.names)
+    for k in self.buffers:
+        if k in msd:
+            self.buffers[k].copy_(msd[k].float())
+    for k in self.nbt:
+        if k in msd:
+            self.nbt[k] = int(msd[k])
+    for k in list(self.other):
+        if k in msd:
+            self.other[k] = msd[k].clone()
+    self.key_order = list(msd.keys())
+    shadow = (ck.get("ema_state_dict") or {}).get("shadow")
+    if shadow:
+        put(self.EMA, shadow, [k for k in self.names if k in shadow])
+        if "decay" in ck["ema_state_dict"]:
+            self.hp["ema_decay"] = float(ck["ema_state_dict"]["decay"])
+    else:
+        self.EMA.copy_(self.P)                                        # train.py:965: EMA re-initialised from the model weights
+    if load_optimizer and "optimizer_state_dict" in ck:
+        osd = ck["optimizer_state_dict"]
+        pkeys = [k for k in msd if is_parameter_key(k) and not k.startswith("expert_ensemble.")]
+        steps = set()
+        self.M.zero_()
+        self.V.zero_()
+        for i, st in osd["state"].items():
+            k = pkeys[int(i)]
+            if k in self.offs:
+                put(self.M, {k: st["exp_avg"]}, [k])
+                put(self.V, {k: st["exp_avg_sq"]}, [k])
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise _lib.FFError(f"optimizer state carries different step counts {sorted(steps)}: per-parameter steps are not supported")
+        self.step_count = steps.pop() if steps else 0
+        g = osd["param_groups"][0]
+        self.hp.update(lr=float(g.get("initial_lr", g["lr"])), betas=tuple(g["betas"]), eps=float(g["eps"]), weight_decay=float(g["weight_decay"]))
+    if "ff_trainer" in ck:
+        self.seed, self.dropout = int(ck["ff_trainer"]["seed"]), float(ck["ff_trainer"]["dropout"])
+    return ck
+
+
+FusionTrainer.save_checkpoint = _trainer_save
+FusionTrainer.load_checkpoint = _trainer_load
+FusionTrainer.state_dict_in_order = _state_dict_in_order
+
+
+# ======================================================================================================================
+# Multi-GPU: data-parallel training, one process per GPU, ONE flat all-reduce of the 4 MB gradient buffer per optimizer step
+# (SURVEY 2.1 / 8f rank 1; the reference itself has no distributed code).  Semantics = torch DDP without SyncBatchNorm: every
+# rank runs forward + backward on its own shard of the batch (BatchNorm batch statistics are per rank), gradients are averaged.
+def allreduce_mean_(flat: T, world: int) -> T:
+    import torch.distributed as dist
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / world) if not flat.is_cuda else _scale_inplace(flat, 1.0 / world)
+    return flat
+
+
+def _scale_inplace(flat: T, k: float):
+    ag.k_unary("scale", flat.reshape(1, -1), p0=k, out=flat.reshape(1, -1))
+
+
+def distributed_step(tr: "FusionTrainer", lr, hr, outs, feats, world: int, lr_now: Optional[float] = None) -> T:
+    """One data-parallel step: local forward/backward on this rank's shard, all-reduce(mean) of the flat gradient, identical
+    optimizer step on every rank (parameters stay bit-identical across ranks: same averaged gradient, same deterministic kernels)."""
+    return tr.step(lr, hr, outs, feats, lr_now, grad_hook=lambda g: allreduce_mean_(g, world))

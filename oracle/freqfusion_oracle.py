@@ -29,6 +29,8 @@ Reference map (paths relative to the reference repo root):
   fuse / refine / edge ... src/models/enhanced_fusion.py:502-556, :653-688;
                            src/models/edge_enhancement.py:182-260
   forward ................ src/models/enhanced_fusion.py:694-754
+  train_forward .......... src/models/enhanced_fusion.py:756-812 in training mode, train.py:308-321 (pinned by
+                           tests/golden/train_b2_16.npz: reference outputs, BatchNorm statistics and autograd gradients)
   tiled_forward .......... models/team29_FreqFusion/io.py:82-121
 """
 from __future__ import annotations
@@ -64,9 +66,35 @@ def _conv(x: T, sd: SD, p: str, stride=1, padding=None, groups: int = 1) -> T:
     return F.conv2d(x, w, sd.get(p + ".bias"), stride=stride, padding=padding, groups=groups)
 
 
+class _TrainCtx:
+    """Training-mode switches of the restatement (train_forward below): BatchNorm uses batch statistics and updates ITS OWN copies of
+    the running statistics (`buffers`, one update per module call, momentum 0.1, unbiased variance); the two
+    nn.MultiheadAttention modules drop attention weights with probability `dropout` (torch's RNG stream)."""
+
+    def __init__(self, dropout: float):
+        self.dropout = dropout
+        self.buffers: Dict[str, T] = {}
+        self.calls: Dict[str, int] = {}
+
+
+_TRAIN: Optional[_TrainCtx] = None
+
+
 def _bn(x: T, sd: SD, p: str, eps: float = 1e-5) -> T:
+    if _TRAIN is not None:                                        # nn.BatchNorm2d.forward with self.training
+        rm = _TRAIN.buffers.setdefault(p + ".running_mean", sd[p + ".running_mean"].detach().clone())
+        rv = _TRAIN.buffers.setdefault(p + ".running_var", sd[p + ".running_var"].detach().clone())
+        _TRAIN.calls[p] = _TRAIN.calls.get(p, 0) + 1
+        return F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], True, 0.1, eps)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
                         False, 0.0, eps)
+
+
+def _attn_dropout(a: T) -> T:
+    """nn.MultiheadAttention(dropout=0.1) applies F.dropout to the softmax output in training mode (large_kernel_attention.py:196,296)."""
+    if _TRAIN is not None and _TRAIN.dropout > 0.0:
+        return F.dropout(a, _TRAIN.dropout, True)
+    return a
 
 
 def _bilinear(x: T, size) -> T:
@@ -520,7 +548,7 @@ def cross_band_lka(sd: SD, bands: List[T], p: str = "cross_band_attn", heads: in
     qkv = F.linear(tn, sd[p + ".band_attention.in_proj_weight"], sd[p + ".band_attention.in_proj_bias"])
     d = dim // heads
     q, k, v = [t.reshape(-1, nb, heads, d).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
-    a = torch.softmax((q * d ** -0.5) @ k.transpose(-2, -1), dim=-1) @ v
+    a = _attn_dropout(torch.softmax((q * d ** -0.5) @ k.transpose(-2, -1), dim=-1)) @ v
     a = a.transpose(1, 2).reshape(-1, nb, dim)
     a = F.linear(a, sd[p + ".band_attention.out_proj.weight"], sd[p + ".band_attention.out_proj.bias"]) + tok
     a = a.reshape(b, h, w, nb, dim).permute(0, 3, 4, 1, 2)
@@ -690,7 +718,7 @@ def collaborative(sd: SD, feats: Dict[str, T], outs: List[T], p: str = "collabor
     qkv = F.linear(tn, sd[p + ".cross_attn.in_proj_weight"], sd[p + ".cross_attn.in_proj_bias"])
     d = dim // heads
     q, k, v = [t.reshape(-1, len(names), heads, d).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
-    a = torch.softmax((q * d ** -0.5) @ k.transpose(-2, -1), dim=-1) @ v                   # nn.MultiheadAttention, dropout off in eval
+    a = _attn_dropout(torch.softmax((q * d ** -0.5) @ k.transpose(-2, -1), dim=-1)) @ v    # nn.MultiheadAttention, dropout off in eval
     a = a.transpose(1, 2).reshape(-1, len(names), dim)
     tok = tok + F.linear(a, sd[p + ".cross_attn.out_proj.weight"], sd[p + ".cross_attn.out_proj.bias"])      # :393-395
     tok = tok + _lin(F.gelu(_lin(_ln(tok, sd, p + ".norm2"), sd, p + ".ffn.0")), sd, p + ".ffn.2")           # :396
@@ -720,6 +748,31 @@ def forward_with_precomputed(sd: SD, lr: T, outs: Dict[str, T], feats: Optional[
         if taps is not None:
             taps.update({f"collab.out.{k}": v for k, v in ex.items()})
     return fusion_forward(sd, lr, ex, taps)
+
+
+def train_forward(sd: SD, lr: T, outs: Dict[str, T], feats: Dict[str, T], dropout: float = 0.0):
+    """forward_with_precomputed in TRAINING mode (enhanced_fusion.py:756-812 under model.train(); the body of the reference's
+    train_epoch_cached, train.py:308-318): batch-statistics BatchNorm with running-stat updates, attention dropout, collaborative
+    block live.  Differentiable: pass `sd` tensors with requires_grad to get torch.autograd gradients (the checker of the HIP
+    backward kernels).  Returns (sr before the loop's clamp, {BatchNorm buffer name: updated value}, {module: calls})."""
+    global _TRAIN
+    prev, _TRAIN = _TRAIN, _TrainCtx(dropout)
+    try:
+        enh = collaborative(sd, feats, [outs["hat"], outs["dat"], outs["nafnet"]])
+        sr = fusion_forward(sd, lr, {"hat": enh[0], "dat": enh[1], "nafnet": enh[2]})
+        return sr, _TRAIN.buffers, _TRAIN.calls
+    finally:
+        _TRAIN = prev
+
+
+def train_loss_and_grads(sd: SD, lr: T, hr: T, outs: Dict[str, T], feats: Dict[str, T], names: List[str], dropout: float = 0.0):
+    """loss = mean |clamp(sr, 0, 1) - hr| (CombinedLoss with the stage-1 weights {l1: 1}, train.py:318-321) and its gradient wrt the
+    tensors `names` of sd: -> (loss, {name: grad}, sr, buffers)."""
+    leaf = {k: (v.detach().clone().requires_grad_(True) if k in set(names) else v) for k, v in sd.items()}
+    sr, buffers, _ = train_forward(leaf, lr, outs, feats, dropout)
+    loss = (sr.clamp(0, 1) - hr).abs().mean()
+    grads = torch.autograd.grad(loss, [leaf[k] for k in names], allow_unused=True)
+    return float(loss.detach()), {k: g for k, g in zip(names, grads)}, sr.detach(), buffers
 
 
 @torch.no_grad()

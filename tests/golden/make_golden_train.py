@@ -110,8 +110,8 @@ def run_case(tag):
         loss = (sr - d["hr"]).abs().mean()
         loss.backward()
         if step == 0:
-            blob["sr"] = sr.detach().numpy().astype(np.float32) if sr.numel() <= (1 << 22) else np.zeros(0, np.float32)
-            if sr.numel() > (1 << 22):
+            blob["sr"] = sr.detach().numpy().astype(np.float32) if sr.numel() <= (1 << 20) else np.zeros(0, np.float32)
+            if sr.numel() > (1 << 20):
                 idx = sidx("sr", sr.numel(), 65536)
                 blob["sr/idx"], blob["sr/val"] = idx, sr.detach().reshape(-1).numpy()[idx].astype(np.float32)
             nograd = []
