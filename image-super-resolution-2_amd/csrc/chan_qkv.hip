@@ -35,6 +35,7 @@ struct ChanQkvParams {
 #define CQ_OFF_BS (CQ_OFF_TR + 8 * 32 * CQ_TR * 4)
 #define CQ_LDS (CQ_OFF_BS + 18 * 32 * 4)
 
+template <int NTERMS>
 __global__ __launch_bounds__(512) void chan_qkv_kernel(ChanQkvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem + CQ_OFF_RED);
@@ -125,12 +126,16 @@ __global__ __launch_bounds__(512) void chan_qkv_kernel(ChanQkvParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
       if (!swap) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[st], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], acc, 0, 0, 0);
+        if (NTERMS == 3) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[st], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], acc, 0, 0, 0);
+        }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], acc, 0, 0, 0);
       } else {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[st], ah, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[st], al, acc, 0, 0, 0);
+        if (NTERMS == 3) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[st], ah, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[st], al, acc, 0, 0, 0);
+        }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[st], ah, acc, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -179,8 +184,10 @@ __global__ __launch_bounds__(512) void chan_qkv_kernel(ChanQkvParams p) {
     for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {                          // G[i][j] += sum over this wave's tokens of q[t][i] k[t][j]
-      g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[s], kl[s], g, 0, 0, 0);
-      g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[s], kh[s], g, 0, 0, 0);
+      if (NTERMS == 3) {
+        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[s], kl[s], g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[s], kh[s], g, 0, 0, 0);
+      }
       g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[s], kh[s], g, 0, 0, 0);
     }
     float* rw = red + wid * CQ_RED;
@@ -238,7 +245,8 @@ extern "C" long long ff_chan_qkv_workspace(long long M) { return ((M + 255) / 25
 
 extern "C" int ff_chan_qkv(const float* x, int ldx, long long M, int K, const float* gamma, const float* beta, float eps,
                            const void* w_tiles, const float* bias_padded, float* v_out, int ldv, float* work, long long work_floats,
-                           void* stream) {
+                           int nterms, void* stream) {
+  FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_chan_qkv: nterms must be 1 or 3");
   FF_CHECK_ARG(x && gamma && beta && w_tiles && v_out && work && M > 0, "ff_chan_qkv: null pointer");
   FF_CHECK_ARG(K == 180 && ldx >= K && ldx % 4 == 0 && ldv >= K && ldv % 4 == 0, "ff_chan_qkv: built for DAT's 180 channels (6 heads of 30), 16-byte aligned rows");
   FF_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)v_out) | ((uintptr_t)w_tiles) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0, "ff_chan_qkv: 16-byte alignment");
@@ -251,11 +259,13 @@ extern "C" int ff_chan_qkv(const float* x, int ldx, long long M, int K, const fl
   static_assert(8 * 32 * FF_XS_ROW * 4 <= 8 * CQ_RED * 4 + 8 * 32 * CQ_TR * 4, "gather patch must fit in the reduction + transpose area");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_qkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CQ_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_qkv_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, CQ_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_qkv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, CQ_LDS);
     if (e != hipSuccess) { ff_set_error("ff_chan_qkv: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(chan_qkv_kernel, dim3((unsigned)nblk), dim3(512), CQ_LDS, (hipStream_t)stream, p);
+  if (nterms == 3) hipLaunchKernelGGL(chan_qkv_kernel<3>, dim3((unsigned)nblk), dim3(512), CQ_LDS, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(chan_qkv_kernel<1>, dim3((unsigned)nblk), dim3(512), CQ_LDS, (hipStream_t)stream, p);
   FF_LAUNCH_CHECK("ff_chan_qkv");
   return FF_OK;
 }

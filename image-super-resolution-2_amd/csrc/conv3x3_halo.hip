@@ -31,7 +31,8 @@ struct HaloParams {
 // WK = input channels per weight tile (64: one tile per (chunk, tap); 32: two).  The 192-channel configuration uses
 // 16x16-pixel workgroups (weights are re-streamed per workgroup: 256 pixels per fetch halve the L2 traffic that bounds
 // the 128-pixel form) and 32-channel weight tiles so that the 88 KB input tile and the ring still fit in 160 KB.
-template <int WM, int WN, int MI, int NI, int WK, int ACT, int NSLOT>
+// NTERMS = 3: split-bf16 products (fp32-grade); 1: plain bf16 (hi x hi only; the lo halves of the LDS rows are written but never read).
+template <int WM, int WN, int MI, int NI, int WK, int ACT, int NSLOT, int NTERMS>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p) {
   constexpr int NW = WM * WN, NT = NW * 64;            // 4 or 8 waves
   static_assert(NW == 4 || NW == 8, "four or eight waves");
@@ -178,8 +179,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              if (NTERMS == 3) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              }
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
         }
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
   }
 }
 
-template <int WM, int WN, int MI, int NI, int WK, int NSLOT>
+template <int WM, int WN, int MI, int NI, int WK, int NSLOT, int NTERMS>
 static int launch_halo(HaloParams& p, hipStream_t st) {
   constexpr int TH = WM * MI * 2, BN = WN * NI * 32;
   constexpr int WSLOT = ((BN * (WK * 4 + 16) + 1023) / 1024) * 1024;
@@ -283,12 +286,12 @@ static int launch_halo(HaloParams& p, hipStream_t st) {
     constexpr int ACT = decltype(A)::value;
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, MI, NI, WK, ACT, NSLOT>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WM, WN, MI, NI, WK, ACT, NSLOT, NTERMS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { ff_set_error("ff_conv3x3_halo: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); attr_failed = true; return; }
       attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, MI, NI, WK, ACT, NSLOT>), dim3((unsigned)nblocks), dim3(WM * WN * 64), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, MI, NI, WK, ACT, NSLOT, NTERMS>), dim3((unsigned)nblocks), dim3(WM * WN * 64), lds, st, p);
   };
   FF_DISPATCH_ACT(p.act, go);
   if (attr_failed) return FF_ERR_LAUNCH;
@@ -313,7 +316,8 @@ extern "C" long long ff_conv3x3_halo_pool_rows(int B, int H, int W, int Cout, in
 
 extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const float* bias, const float* mul,
                                const float* res, int ldr, float* out, int ldo, int B, int H, int W, int Cin, int Cout,
-                               int act, float alpha, int shuffle, float* pool_partials, void* stream) {
+                               int act, float alpha, int shuffle, float* pool_partials, int nterms, void* stream) {
+  FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_conv3x3_halo: nterms must be 1 or 3");
   FF_CHECK_ARG(in && w_img && out, "ff_conv3x3_halo: null pointer");
   FF_CHECK_ARG(!pool_partials || (shuffle == 0 && Cout <= bn), "ff_conv3x3_halo: pool partials need Cout <= bn and no pixel shuffle");
   FF_CHECK_ARG(shuffle == 0 || (shuffle == 2 && Cout % 4 == 0), "ff_conv3x3_halo: shuffle must be 0 or 2 (Cout %% 4 == 0)");
@@ -331,10 +335,10 @@ extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int 
   switch (bn) {
     // 16x16-pixel workgroups of 8 waves (two per SIMD: one wave's LDS reads and waits hide behind the
     // other's MFMAs -- measured 140 -> 121 us for 180->180 against the 4-wave form)
-    case 32: return launch_halo<8, 1, 1, 1, 64, 2>(p, st);    // wave: 32 pixels x 32 channels
-    case 64: return launch_halo<8, 1, 1, 2, 64, 2>(p, st);    // wave: 32 pixels x 64
-    case 128: return launch_halo<2, 2, 2, 2, 64, 2>(p, st);   // 8x16 pixels, 4 waves (only the two up-sampling convolutions use it)
-    case 192: return launch_halo<4, 2, 2, 3, 32, 2>(p, st);   // 16x16 pixels x 192, 8 waves (2 per SIMD), 32-channel weight tiles; 88 KB tile + 2 x 27 KB ring
+    case 32: return nterms == 3 ? launch_halo<8, 1, 1, 1, 64, 2, 3>(p, st) : launch_halo<8, 1, 1, 1, 64, 2, 1>(p, st);    // wave: 32 pixels x 32 channels
+    case 64: return nterms == 3 ? launch_halo<8, 1, 1, 2, 64, 2, 3>(p, st) : launch_halo<8, 1, 1, 2, 64, 2, 1>(p, st);    // wave: 32 pixels x 64
+    case 128: return nterms == 3 ? launch_halo<2, 2, 2, 2, 64, 2, 3>(p, st) : launch_halo<2, 2, 2, 2, 64, 2, 1>(p, st);   // 8x16 pixels, 4 waves (only the two up-sampling convolutions use it)
+    case 192: return nterms == 3 ? launch_halo<4, 2, 2, 3, 32, 2, 3>(p, st) : launch_halo<4, 2, 2, 3, 32, 2, 1>(p, st);   // 16x16 pixels x 192, 8 waves (2 per SIMD), 32-channel weight tiles; 88 KB tile + 2 x 27 KB ring
     default: ff_set_error("ff_conv3x3_halo: bn must be 32, 64, 128 or 192"); return FF_ERR_ARG;
   }
 }

@@ -135,7 +135,7 @@ struct NafFfnParams {
   float eps;
 };
 
-template <int KS>
+template <int KS, int NTERMS>
 __global__ __launch_bounds__(512) void naf_ffn_kernel(NafFfnParams p) {
   constexpr int C = 16 * KS, GT = C / 32, NTO = C / 32;
   constexpr int W1SLOTS = 2 * KS + 1, W1ROWB = W1SLOTS * 16, W1PL = 32 * W1SLOTS;      // per plane (one 32-row tile)
@@ -259,10 +259,12 @@ __global__ __launch_bounds__(512) void naf_ffn_kernel(NafFfnParams p) {
         const bf16x8 b_h = *reinterpret_cast<const bf16x8*>(ap + 32 * st + 2 * W1B);
         const bf16x8 b_l = *reinterpret_cast<const bf16x8*>(ap + 32 * st + 3 * W1B);
         const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xl_row + 32 * st);
-        ha = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, xl, ha, 0, 0, 0);
-        hb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_h, xl, hb, 0, 0, 0);
-        ha = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, xh[st], ha, 0, 0, 0);
-        hb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_l, xh[st], hb, 0, 0, 0);
+        if (NTERMS == 3) {
+          ha = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, xl, ha, 0, 0, 0);
+          hb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_h, xl, hb, 0, 0, 0);
+          ha = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, xh[st], ha, 0, 0, 0);
+          hb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_l, xh[st], hb, 0, 0, 0);
+        }
         ha = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, xh[st], ha, 0, 0, 0);
         hb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_h, xh[st], hb, 0, 0, 0);
       }
@@ -288,8 +290,10 @@ __global__ __launch_bounds__(512) void naf_ffn_kernel(NafFfnParams p) {
         const unsigned char* ap = W2s + (n * 32 + l31) * W2ROWB + 32 * s + 16 * hh;
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
         const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + W2B);
-        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl[s], oacc[n], 0, 0, 0);
-        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh[s], oacc[n], 0, 0, 0);
+        if (NTERMS == 3) {
+          oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl[s], oacc[n], 0, 0, 0);
+          oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh[s], oacc[n], 0, 0, 0);
+        }
         oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh[s], oacc[n], 0, 0, 0);
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W4(g+1) pieces landed
@@ -330,27 +334,28 @@ __global__ __launch_bounds__(512) void naf_ffn_kernel(NafFfnParams p) {
   }
 }
 
-template <int KS>
+template <int KS, int NTERMS>
 static int launch_naf_ffn(const NafFfnParams& p, hipStream_t st) {
   constexpr int C = 16 * KS;
   const size_t lds = (size_t)4 * 32 * (2 * KS + 1) * 16 + (size_t)2 * C * 5 * 16 + (size_t)8 * 32 * (KS * 32 + 16) + (size_t)2 * C * 4 +
                      (KS >= 8 ? 0 : (size_t)8 * 32 * FF_XS_ROW * 4);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&naf_ffn_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&naf_ffn_kernel<KS, NTERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { ff_set_error("ff_naf_ffn: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
     attr_set = true;
   }
   const long long nblk = (p.M + 255) / 256;
   if (nblk >= (1LL << 31)) { ff_set_error("ff_naf_ffn: grid too large"); return FF_ERR_ARG; }
-  hipLaunchKernelGGL(naf_ffn_kernel<KS>, dim3((unsigned)nblk), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((naf_ffn_kernel<KS, NTERMS>), dim3((unsigned)nblk), dim3(512), lds, st, p);
   FF_LAUNCH_CHECK("ff_naf_ffn");
   return FF_OK;
 }
 
 extern "C" int ff_naf_ffn(const float* y, int ldy, float* out, int ldo, long long M, int C, const float* gamma_ln,
                           const float* beta_ln, float eps, const void* w_tiles, const float* b4, const float* b5,
-                          const float* out_scale, void* stream) {
+                          const float* out_scale, int nterms, void* stream) {
+  FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_naf_ffn: nterms must be 1 or 3");
   FF_CHECK_ARG(y && out && gamma_ln && beta_ln && w_tiles && b4 && b5 && out_scale, "ff_naf_ffn: null pointer");
   FF_CHECK_ARG(M > 0 && (C == 64 || C == 128), "ff_naf_ffn: C must be 64 or 128");
   FF_CHECK_ARG(ldy >= C && ldy % 4 == 0 && ldo >= C && (((uintptr_t)y) & 15) == 0 && (((uintptr_t)w_tiles) & 15) == 0 &&
@@ -358,7 +363,8 @@ extern "C" int ff_naf_ffn(const float* y, int ldy, float* out, int ldo, long lon
   NafFfnParams p;
   p.y = y; p.out = out; p.gamma_ln = gamma_ln; p.beta_ln = beta_ln; p.w = (const __bf16*)w_tiles; p.b4 = b4; p.b5 = b5;
   p.oscale = out_scale; p.M = M; p.ldy = ldy; p.ldo = ldo; p.eps = eps;
-  return C == 64 ? launch_naf_ffn<4>(p, (hipStream_t)stream) : launch_naf_ffn<8>(p, (hipStream_t)stream);
+  if (nterms == 3) return C == 64 ? launch_naf_ffn<4, 3>(p, (hipStream_t)stream) : launch_naf_ffn<8, 3>(p, (hipStream_t)stream);
+  return C == 64 ? launch_naf_ffn<4, 1>(p, (hipStream_t)stream) : launch_naf_ffn<8, 1>(p, (hipStream_t)stream);
 }
 
 #include "naf_front.inc"

@@ -34,7 +34,9 @@ struct TokenLinParams {
 
 #define TL_TR 36   // floats per row of the transpose patch: 144 B keeps rows 16-byte aligned and ds_*_b128 conflict-free
 
-template <int ACT, int TL_KS, bool VEC4, bool GATED = false>
+// NTERMS = 3: split-bf16 products hi*lo + lo*hi + hi*hi (fp32-grade); NTERMS = 1: plain bf16 (hi*hi only: a third of the MFMAs, no lo
+// fragments built or read; the weight image keeps its lo plane, unused).
+template <int ACT, int TL_KS, bool VEC4, bool GATED = false, int NTERMS = 3>
 __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
   constexpr int TL_SLOTS = 2 * TL_KS + 1, TL_ROWB = TL_SLOTS * 16, TL_PL = 32 * TL_SLOTS, TL_PIECES = 2 * TL_PL / 64;
   constexpr int TL_TILE_ELEMS = 32 * 16 * TL_KS, KPAD = 16 * TL_KS;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
           for (int j = 0; j < 8; ++j) {
             const __bf16 h = (__bf16)v[st][j];
             th[st][j] = h;
-            tl[st][j] = (__bf16)(v[st][j] - (float)h);
+            if (NTERMS == 3) tl[st][j] = (__bf16)(v[st][j] - (float)h);
           }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -107,18 +109,20 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         fa[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u);
-        fl[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u + WB);
+        if (NTERMS == 3) fl[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u + WB);
       }
 #pragma unroll
       for (int st = 0; st < TL_KS; ++st) {
         const bf16x8 ah = fa[st & 1], al = fl[st & 1];
         if (st + 2 < TL_KS) {
           fa[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2));
-          fl[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2) + WB);
+          if (NTERMS == 3) fl[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2) + WB);
         }
         __builtin_amdgcn_sched_barrier(0);
-        ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, tl[st], ga, 0, 0, 0);
-        ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, th[st], ga, 0, 0, 0);
+        if (NTERMS == 3) {
+          ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, tl[st], ga, 0, 0, 0);
+          ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, th[st], ga, 0, 0, 0);
+        }
         ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, th[st], ga, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -168,11 +172,15 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
           const float f = (k0 + j < p.K) ? sv * cmv + o * sm : 0.f;
           const __bf16 h = (__bf16)f;
           nh[j] = h;
-          nl[j] = (__bf16)(f - (float)h);
+          if (NTERMS == 3) nl[j] = (__bf16)(f - (float)h);
         }
         xh[st] = nh;
-        xl[st] = nl;
-        asm volatile("" : "+v"(xh[st]), "+v"(xl[st]) : : "memory");            // the pass's fragments are FINISHED here: without this the
+        if (NTERMS == 3) {
+          xl[st] = nl;
+          asm volatile("" : "+v"(xh[st]), "+v"(xl[st]) : : "memory");
+        } else {
+          asm volatile("" : "+v"(xh[st]) : : "memory");
+        }            // the pass's fragments are FINISHED here: without this the
       }                                                                        // scheduler issues every pass's loads first and converts last (raw rows of all passes live)
     }
   } else
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
         const float f = (k0 + j < p.K) ? (p.gamma ? (v[st][j] - mean) * rstd * gg + bb : v[st][j]) : 0.f;
         const __bf16 h = (__bf16)f;
         xh[st][j] = h;
-        xl[st][j] = (__bf16)(f - (float)h);
+        if (NTERMS == 3) xl[st][j] = (__bf16)(f - (float)h);
         v[st][j] = f;
       }
       // side output of the normalised rows (HAT feeds them to the CAB convolution, hat_arch.py:272-274): the separate
@@ -285,18 +293,20 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       fa[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u);
-      fl[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u + WB);
+      if (NTERMS == 3) fl[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u + WB);
     }
 #pragma unroll
     for (int st = 0; st < TL_KS; ++st) {
       const bf16x8 ah = fa[st & 1], al = fl[st & 1];
       if (st + 2 < TL_KS) {
         fa[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2));
-        fl[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2) + WB);
+        if (NTERMS == 3) fl[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2) + WB);
       }
       __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[st], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], acc, 0, 0, 0);
+      if (NTERMS == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[st], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], acc, 0, 0, 0);
+      }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -367,7 +377,8 @@ extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, lon
                                const float* gamma, const float* beta, float eps, const void* w_tiles,
                                const float* bias_padded, int act, const float* res, int ldr, const float* res2, int ldr2,
                                const float* res2_scale, float* xn_out, int ldxn, float* stats_out, int stat_lo, int stat_hi,
-                               float stat_eps, void* stream) {
+                               float stat_eps, int nterms, void* stream) {
+  FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_token_linear: nterms must be 1 (plain bf16) or 3 (split bf16)");
   FF_CHECK_ARG(x && out && w_tiles, "ff_token_linear: null pointer");
   FF_CHECK_ARG(M > 0 && K > 0 && K <= 192 && K % 4 == 0 && N > 0 && n_tiles * 32 >= N, "ff_token_linear: needs K <= 192 (K %% 4 == 0), n_tiles*32 >= N");
   FF_CHECK_ARG(kpad == 64 || kpad == 128 || kpad == 192, "ff_token_linear: kpad must be 64, 128 or 192");
@@ -393,21 +404,23 @@ extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, lon
   FF_CHECK_ARG(act == ACT_NONE || act == ACT_GELU, "ff_token_linear: act must be none or gelu");
   const long long nblk = (M + 255) / 256;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_linear: grid too large");
-#define TL_LAUNCH(A, KSV, V4)                                                                                               \
+#define TL_LAUNCH(A, KSV, V4, NTM)                                                                                          \
   do {                                                                                                                      \
     static bool attr_set = false;                                                                                           \
     if (!attr_set) {                                                                                                        \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<A, KSV, V4>),                   \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<A, KSV, V4, false, NTM>),       \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
       if (e != hipSuccess) { ff_set_error("ff_token_linear: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; } \
       attr_set = true;                                                                                                      \
     }                                                                                                                       \
-    hipLaunchKernelGGL((token_linear_kernel<A, KSV, V4>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);    \
+    hipLaunchKernelGGL((token_linear_kernel<A, KSV, V4, false, NTM>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p); \
   } while (0)
-#define TL_LAUNCH_KS(A, V4) do { if (ks == 4) TL_LAUNCH(A, 4, V4); else if (ks == 8) TL_LAUNCH(A, 8, V4); else TL_LAUNCH(A, 12, V4); } while (0)
+#define TL_LAUNCH_NT(A, KSV, V4) do { if (nterms == 3) TL_LAUNCH(A, KSV, V4, 3); else TL_LAUNCH(A, KSV, V4, 1); } while (0)
+#define TL_LAUNCH_KS(A, V4) do { if (ks == 4) TL_LAUNCH_NT(A, 4, V4); else if (ks == 8) TL_LAUNCH_NT(A, 8, V4); else TL_LAUNCH_NT(A, 12, V4); } while (0)
   if (act == ACT_GELU) { if (vec4) TL_LAUNCH_KS(ACT_GELU, true); else TL_LAUNCH_KS(ACT_GELU, false); }
   else { if (vec4) TL_LAUNCH_KS(ACT_NONE, true); else TL_LAUNCH_KS(ACT_NONE, false); }
 #undef TL_LAUNCH_KS
+#undef TL_LAUNCH_NT
 #undef TL_LAUNCH
   FF_LAUNCH_CHECK("ff_token_linear");
   return FF_OK;
@@ -419,7 +432,9 @@ extern "C" int ff_token_linear(const float* x, int ldx, float* out, int ldo, lon
 // (11 hidden units, BatchNorm folded), gb1 / gw2: [12].
 extern "C" int ff_token_linear_gated(const float* x, int ldx, const float* x2, int ldx2, const float* cm, const float* gw1t,
                                      const float* gb1, const float* gw2, float gb2, float* out, int ldo, long long M, int K, int N,
-                                     int n_tiles, const void* w_tiles, const float* bias_padded, const float* res, int ldr, void* stream) {
+                                     int n_tiles, const void* w_tiles, const float* bias_padded, const float* res, int ldr, int nterms,
+                                     void* stream) {
+  FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_token_linear_gated: nterms must be 1 or 3");
   FF_CHECK_ARG(x && x2 && cm && gb1 && gw2 && out && w_tiles, "ff_token_linear_gated: null pointer");   /* gw1t is unused: GW1 travels as tile n_tiles of w_tiles */
   FF_CHECK_ARG(M > 0 && K > 0 && K <= 192 && K % 4 == 0 && N > 0 && N % 4 == 0 && n_tiles * 32 >= N, "ff_token_linear_gated: needs K <= 192, K and N multiples of 4");
   FF_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldx2 >= K && ldx2 % 4 == 0 && ldo >= N && ldo % 4 == 0 && (!res || (ldr >= N && ldr % 4 == 0)), "ff_token_linear_gated: rows must be 16-byte aligned");
@@ -436,12 +451,16 @@ extern "C" int ff_token_linear_gated(const float* x, int ldx, const float* x2, i
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_linear_gated: grid too large");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<ACT_NONE, 12, true, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<ACT_NONE, 12, true, true, 3>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<ACT_NONE, 12, true, true, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { ff_set_error("ff_token_linear_gated: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((token_linear_kernel<ACT_NONE, 12, true, true>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  if (nterms == 3) hipLaunchKernelGGL((token_linear_kernel<ACT_NONE, 12, true, true, 3>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((token_linear_kernel<ACT_NONE, 12, true, true, 1>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
   FF_LAUNCH_CHECK("ff_token_linear_gated");
   return FF_OK;
 }

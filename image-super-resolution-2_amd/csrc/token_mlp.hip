@@ -47,7 +47,7 @@ struct TokenMlpParams {
   float eps;
 };
 
-template <bool VEC4>
+template <bool VEC4, int NTERMS>
 __global__ __launch_bounds__(512) void token_mlp_kernel(TokenMlpParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int W1B = W1PL * 16, W2B = W2PL * 16;
@@ -175,8 +175,10 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(TokenMlpParams p) {
           fx[st & 1] = *reinterpret_cast<const bf16x8*>(xl_row + 32 * (st + 2));
         }
         __builtin_amdgcn_sched_barrier(0);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, hacc, 0, 0, 0);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], hacc, 0, 0, 0);
+        if (NTERMS == 3) {
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, hacc, 0, 0, 0);
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], hacc, 0, 0, 0);
+        }
         hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], hacc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -213,8 +215,10 @@ __global__ __launch_bounds__(512) void token_mlp_kernel(TokenMlpParams p) {
           fl[u & 1] = *reinterpret_cast<const bf16x8*>(ap + ((u + 2) >> 1) * 32 * W2ROWB + 32 * ((u + 2) & 1) + W2B);
         }
         __builtin_amdgcn_sched_barrier(0);
-        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl[s2], oacc[n], 0, 0, 0);
-        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh[s2], oacc[n], 0, 0, 0);
+        if (NTERMS == 3) {
+          oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl[s2], oacc[n], 0, 0, 0);
+          oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh[s2], oacc[n], 0, 0, 0);
+        }
         oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh[s2], oacc[n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -333,6 +337,7 @@ struct TokenProjMlpParams {
   float eps;
 };
 
+template <int NTERMS>
 __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int W1B = W1PL * 16, W2B = W2PL * 16;
@@ -434,8 +439,10 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
         fx[st & 1] = *reinterpret_cast<const bf16x8*>(xl_row + 32 * (st + 2));
       }
       __builtin_amdgcn_sched_barrier(0);
-      oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, oacc[n], 0, 0, 0);
-      oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], oacc[n], 0, 0, 0);
+      if (NTERMS == 3) {
+        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, oacc[n], 0, 0, 0);
+        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], oacc[n], 0, 0, 0);
+      }
       oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], oacc[n], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -542,8 +549,10 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
           fx[st & 1] = *reinterpret_cast<const bf16x8*>(xl_row + 32 * (st + 2));
         }
         __builtin_amdgcn_sched_barrier(0);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, hacc, 0, 0, 0);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], hacc, 0, 0, 0);
+        if (NTERMS == 3) {
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, hacc, 0, 0, 0);
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[st], hacc, 0, 0, 0);
+        }
         hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], hacc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -578,8 +587,10 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
           fl[u & 1] = *reinterpret_cast<const bf16x8*>(ap + ((u + 2) >> 1) * 32 * W2ROWB + 32 * ((u + 2) & 1) + W2B);
         }
         __builtin_amdgcn_sched_barrier(0);
-        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl[s2], oacc[n], 0, 0, 0);
-        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh[s2], oacc[n], 0, 0, 0);
+        if (NTERMS == 3) {
+          oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl[s2], oacc[n], 0, 0, 0);
+          oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh[s2], oacc[n], 0, 0, 0);
+        }
         oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh[s2], oacc[n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -621,7 +632,8 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
 extern "C" int ff_token_projmlp(const float* att, int lda, const float* x, int ldx, const float* c2, int ldc, const float* c2_scale,
                                 float* out, int ldo, long long M, int K, int hidden_tiles, const void* proj_tiles,
                                 const float* proj_bias_padded, const float* gamma, const float* beta, float eps,
-                                const void* mlp_tiles, const float* b1_padded, const float* b2, void* stream) {
+                                const void* mlp_tiles, const float* b1_padded, const float* b2, int nterms, void* stream) {
+  FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_token_projmlp: nterms must be 1 or 3");
   FF_CHECK_ARG(att && x && out && proj_tiles && proj_bias_padded && gamma && beta && mlp_tiles && b1_padded && b2, "ff_token_projmlp: null pointer");
   FF_CHECK_ARG(M > 0 && K > 0 && K <= TM_KP && K % 4 == 0 && hidden_tiles > 0, "ff_token_projmlp: needs K <= 192 (K %% 4 == 0)");
   FF_CHECK_ARG(lda >= K && lda % 4 == 0 && ldx >= K && ldx % 4 == 0 && ldo >= K && ldo % 4 == 0, "ff_token_projmlp: rows must be 16-byte aligned");
@@ -640,18 +652,21 @@ extern "C" int ff_token_projmlp(const float* att, int lda, const float* x, int l
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_projmlp: grid too large");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_projmlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_projmlp_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_projmlp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { ff_set_error("ff_token_projmlp: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(token_projmlp_kernel, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  if (nterms == 3) hipLaunchKernelGGL(token_projmlp_kernel<3>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(token_projmlp_kernel<1>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
   FF_LAUNCH_CHECK("ff_token_projmlp");
   return FF_OK;
 }
 
 extern "C" int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long long M, int K, int hidden_tiles, int N,
                             const float* gamma, const float* beta, float eps, const void* w_tiles, const float* b1_padded,
-                            const float* b2, void* stream) {
+                            const float* b2, int nterms, void* stream) {
+  FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_token_mlp: nterms must be 1 or 3");
   FF_CHECK_ARG(x && out && gamma && beta && w_tiles && b1_padded && b2, "ff_token_mlp: null pointer");
   FF_CHECK_ARG(M > 0 && K > 0 && K <= TM_KP && K % 4 == 0 && N > 0 && N <= TM_NP && hidden_tiles > 0, "ff_token_mlp: needs K, N <= 192 (K %% 4 == 0)");
   FF_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldo >= N && (((uintptr_t)x) & 15) == 0, "ff_token_mlp: x rows must be 16-byte aligned");
@@ -665,18 +680,19 @@ extern "C" int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long l
   FF_CHECK_ARG(lds <= 160 * 1024, "ff_token_mlp: hidden too large for the LDS image");
   const long long nblk = (M + 255) / 256;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_mlp: grid too large");
-#define TM_LAUNCH(V4)                                                                                                      \
+#define TM_LAUNCH(V4, NTM)                                                                                                 \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \
     if (!attr_set) {                                                                                                       \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_mlp_kernel<V4>),                             \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_mlp_kernel<V4, NTM>),                        \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
       if (e != hipSuccess) { ff_set_error("ff_token_mlp: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; } \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    hipLaunchKernelGGL(token_mlp_kernel<V4>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);                \
+    hipLaunchKernelGGL((token_mlp_kernel<V4, NTM>), dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);         \
   } while (0)
-  if (vec4) TM_LAUNCH(true); else TM_LAUNCH(false);
+  if (nterms == 3) { if (vec4) TM_LAUNCH(true, 3); else TM_LAUNCH(false, 3); }
+  else { if (vec4) TM_LAUNCH(true, 1); else TM_LAUNCH(false, 1); }
 #undef TM_LAUNCH
   FF_LAUNCH_CHECK("ff_token_mlp");
   return FF_OK;

@@ -53,7 +53,7 @@ def _tl(blk: dict, key: str) -> dict:
 
 def _fast() -> bool:
     """The token-stationary fused kernels exist for the default split-bf16 contraction only."""
-    return ops.gemm_mode() == "bf16x3"
+    return ops.fused_modes()
 
 
 # Window-resident attention block (LayerNorm + qkv + attention in one launch, csrc/win_attn_fused.hip); FF_WIN_FUSED=0 keeps
@@ -164,7 +164,7 @@ class HatHIP:
 
     # -- blocks -------------------------------------------------------------------------------
     def _mlp(self, x: T, blk: dict) -> T:
-        if ops.gemm_mode() == "bf16x3":                      # fused LN + fc1 + GELU + fc2 + residual, hidden stays on chip
+        if ops.fused_modes():                                # fused LN + fc1 + GELU + fc2 + residual, hidden stays on chip
             if "mlp_pk" not in blk:
                 blk["mlp_pk"] = pack_token_mlp(blk["fc1"][0], blk["fc1"][1], blk["fc2"][0], blk["fc2"][1])
             return ops.token_mlp(x, blk["n2"][0], blk["n2"][1], blk["mlp_pk"])

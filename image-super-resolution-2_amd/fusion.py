@@ -141,7 +141,7 @@ class CrossBandLKA:
         for i in range(nb):
             ops.linear(bands[..., 3 * i:3 * i + 3], *self.proj, out=tok[..., E * i:E * (i + 1)])
         rows = tok.reshape(P * nb, E)                                   # token (pixel, band) rows
-        fast = ops.gemm_mode() == "bf16x3"
+        fast = ops.fused_modes()
         if fast:
             qkv = ops.token_linear(rows, self.tl_in, gamma=self.norm[0], beta=self.norm[1])          # LayerNorm + in_proj
         else:

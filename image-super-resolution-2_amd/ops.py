@@ -87,6 +87,18 @@ def set_gemm_mode(mode: str):
     _GEMM_MODE = mode
 
 
+def _nterms() -> int:
+    """MFMA terms per product of the fused token / halo / NAFNet kernels: 3 (split bf16, fp32-grade) or 1 (plain bf16)."""
+    if _GEMM_MODE not in ("bf16x3", "bf16"):
+        raise _lib.FFError(f"the fused bf16 kernels exist for the 'bf16x3' and 'bf16' contraction modes, not {_GEMM_MODE!r}")
+    return 3 if _GEMM_MODE == "bf16x3" else 1
+
+
+def fused_modes() -> bool:
+    """True in the contraction modes that have the fused (token-stationary, window-resident, LDS-resident 3x3) kernels."""
+    return _GEMM_MODE in ("bf16x3", "bf16")
+
+
 def gemm_mode() -> str:
     return _GEMM_MODE
 
@@ -347,7 +359,7 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
         _lib.check(_L().ff_conv2d(xp, w.data_ptr(), _ptr(bias), _ptr(mul), rp, op, B, H, W, Cin, ldi, Ho, Wo, Cout, ldo, ldr,
                                   KH, KW, stride[0], stride[1], pad[0], pad[1], ACT[act], float(alpha), shuffle, tile_hint,
                                   _stream()))
-    elif (_HALO and _GEMM_MODE == "bf16x3" and (KH, KW) == (3, 3) and tuple(stride) == (1, 1) and tuple(pad) == (1, 1)
+    elif (_HALO and _GEMM_MODE in ("bf16x3", "bf16") and (KH, KW) == (3, 3) and tuple(stride) == (1, 1) and tuple(pad) == (1, 1)
           and not dynamic_w and Cin >= 32 and Cin % 4 == 0 and ldi % 4 == 0 and xp % 16 == 0
           and (Cout <= 64 or Cin >= 128 or 128 < Cout <= 192 or _HALO_ALL)   # measured (profiles/r01_conv3x3_halo_vs_igemm.txt); 64 -> 256 ties
           and H * W >= 1024 and xp != op and B * H * W * ldi < 2 ** 31):
@@ -362,7 +374,7 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
             prow = int(_L().ff_conv3x3_halo_pool_rows(B, H, W, Cout, img[1]))
             part = torch.empty((prow, img[1]), device=x.device, dtype=torch.float32)
         _lib.check(_L().ff_conv3x3_halo(xp, ldi, img[0].data_ptr(), img[1], _ptr(bias), _ptr(mul), rp, ldr, op, ldo, B, H, W,
-                                        Cin, Cout, ACT[act], float(alpha), shuffle, _ptr(part), _stream()))
+                                        Cin, Cout, ACT[act], float(alpha), shuffle, _ptr(part), _nterms(), _stream()))
         if part is not None:
             pooled = torch.empty((1, Cout), device=x.device, dtype=torch.float32)
             _lib.check(_L().ff_pool_finish(part.data_ptr(), part.shape[0], img[1], Cout, 1.0 / float(H * W), pooled.data_ptr(), _stream()))
@@ -501,7 +513,7 @@ def token_mlp(x: T, gamma: T, beta: T, pk: dict, eps: float = 1e-5) -> T:
     out = empty_like_rows(x)
     op_, ldo_, _, _ = rows_view(out, "token_mlp.out")
     _lib.check(_L().ff_token_mlp(xp, ldx, op_, ldo_, rows, K, pk["ht"], pk["N"], gamma.data_ptr(), beta.data_ptr(),
-                                 float(eps), pk["w"].data_ptr(), pk["b1"].data_ptr(), pk["b2"].data_ptr(), _stream()))
+                                 float(eps), pk["w"].data_ptr(), pk["b1"].data_ptr(), pk["b2"].data_ptr(), _nterms(), _stream()))
     _note(4.0 * rows * K * pk["ht"] * 32, 8.0 * rows * K)
     return out
 
@@ -524,7 +536,7 @@ def token_projmlp(att: T, x: T, pk: dict, gamma: T, beta: T, *, c2: Optional[T] 
     m = pk["mlp"]
     _lib.check(_L().ff_token_projmlp(ap, lda, xp, ldx, cp, ldc, _ptr(c2_scale), op_, ldo_, rows, K, m["ht"], pk["proj"]["w"].data_ptr(),
                                      pk["proj"]["b"].data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), m["w"].data_ptr(),
-                                     m["b1"].data_ptr(), m["b2"].data_ptr(), _stream()))
+                                     m["b1"].data_ptr(), m["b2"].data_ptr(), _nterms(), _stream()))
     _note(2.0 * rows * K * K + 4.0 * rows * K * m["ht"] * 32, 4.0 * rows * K * (3 + (c2 is not None)))
     return out
 
@@ -565,7 +577,7 @@ def token_linear(x: T, pk: dict, *, gamma: Optional[T] = None, beta: Optional[T]
         sp = stats.data_ptr()
     _lib.check(_L().ff_token_linear(xp, ldx, out.data_ptr(), ldo, rows, K, pk["kpad"], N, pk["nt"], _ptr(gamma), _ptr(beta), float(eps),
                                     pk["w"].data_ptr(), _ptr(pk["b"]), ACT[act], rp, ldr, r2p, ldr2, _ptr(res2_scale), xnp, ldxn,
-                                    sp, slo, shi, float(stats_eps), _stream()))
+                                    sp, slo, shi, float(stats_eps), _nterms(), _stream()))
     _note(2.0 * rows * N * K, 4.0 * (rows * K * (2 if want_xn else 1) + rows * N * (1 + (res is not None) + (res2 is not None))))
     if stats is not None:
         return out, stats
@@ -600,7 +612,7 @@ def naf_front(x: T, pk: dict, ln_g: T, ln_b: T, w_tap: T, dw_bias: T, eps: float
     work = torch.empty(nwork, device=x.device, dtype=torch.float32)
     _lib.check(_L().ff_naf_front(xp, ldx, H, W, C, ln_g.data_ptr(), ln_b.data_ptr(), float(eps), pk["w"].data_ptr(), pk["b"].data_ptr(),
                                  w_tap.data_ptr(), dw_bias.data_ptr(), out.data_ptr(), C, pooled.data_ptr(), work.data_ptr(), nwork,
-                                 _stream()))
+                                 _nterms(), _stream()))
     _note(2.0 * H * W * 2 * C * (C + 9), 4.0 * H * W * 2 * C)
     return out, pooled
 
@@ -612,7 +624,7 @@ def naf_ffn(y: T, pk: dict, ln_g: T, ln_b: T, out_scale: T, eps: float = 1e-6) -
         raise _lib.FFError("naf_ffn: channel mismatch")
     out = torch.empty(tuple(y.shape), device=y.device, dtype=torch.float32)
     _lib.check(_L().ff_naf_ffn(yp, ldy, out.data_ptr(), C, rows, C, ln_g.data_ptr(), ln_b.data_ptr(), float(eps), pk["w"].data_ptr(),
-                               pk["b4"].data_ptr(), pk["b5"].data_ptr(), out_scale.data_ptr(), _stream()))
+                               pk["b4"].data_ptr(), pk["b5"].data_ptr(), out_scale.data_ptr(), _nterms(), _stream()))
     _note(2.0 * rows * C * 3 * C, 8.0 * rows * C)
     return out
 
@@ -706,7 +718,7 @@ def token_linear_gated(x: T, x2: T, pk: dict, cm: T, gb2: float, *, res: Optiona
         if rr != rows or rc != N:
             raise _lib.FFError("token_linear_gated: res shape mismatch")
     _lib.check(_L().ff_token_linear_gated(xp, ldx, x2p, ldx2, cm.data_ptr(), None, pk["gb1"].data_ptr(), pk["gw2"].data_ptr(), float(gb2),
-                                          op, ldo, rows, K, N, pk["nt"], pk["w"].data_ptr(), pk["b"].data_ptr(), rp, ldr, _stream()))
+                                          op, ldo, rows, K, N, pk["nt"], pk["w"].data_ptr(), pk["b"].data_ptr(), rp, ldr, _nterms(), _stream()))
     _note(2.0 * rows * N * K + 2.0 * rows * 32 * K, 4.0 * rows * (2 * K + N * (2 if res is not None else 1)))
     return out
 
@@ -946,7 +958,7 @@ def chan_qkv_attn(x: T, pk: dict, gamma: T, beta: T, temperature: T, eps: float 
     work = torch.empty(nwork, device=x.device, dtype=torch.float32)
     wbd = torch.empty((180, 180), device=x.device, dtype=torch.float32)
     _lib.check(_L().ff_chan_qkv(xp, ldx, rows, K, gamma.data_ptr(), beta.data_ptr(), float(eps), pk["w"].data_ptr(), pk["b"].data_ptr(),
-                                vp, ldv, work.data_ptr(), nwork, _stream()))
+                                vp, ldv, work.data_ptr(), nwork, _nterms(), _stream()))
     _lib.check(_L().ff_chan_attn_finish(work.data_ptr(), nwork, (rows + 255) // 256, temperature.data_ptr(), wbd.data_ptr(), _stream()))
     _note(2.0 * rows * 576 * K + 2.0 * rows * 6 * 32 * 32, 8.0 * rows * K)
     return v, wbd

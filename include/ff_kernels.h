@@ -98,11 +98,13 @@ int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_off, int v_
  *   x1 = x + proj(att) + c2 * c2_scale;  out = x1 + fc2(GELU(fc1(LayerNorm(x1))))        (hat_arch.py:303-307, OCAB :434-437)
  * x1 never reaches memory.  proj_tiles / proj_bias_padded: ff_token_linear's weight format for the 180 -> 180 projection;
  * mlp_tiles: ff_token_mlp's format with fc1's K columns in the accumulator-operand order (prep.pack_token_projmlp);
- * c2 / c2_scale may be NULL (no convolution branch).  K = N <= 192, bf16x3. */
+ * c2 / c2_scale may be NULL (no convolution branch).  K = N <= 192.
+ * nterms (here and in every token / halo / NAFNet kernel below): 3 = split-bf16 products hi*lo + lo*hi + hi*hi (fp32-grade results),
+ * 1 = plain bf16 operands (hi*hi only: a third of the MFMAs; the weight images are the same, their lo planes unused). */
 int ff_token_projmlp(const float* att, int lda, const float* x, int ldx, const float* c2, int ldc, const float* c2_scale,
                      float* out, int ldo, long long M, int K, int hidden_tiles, const void* proj_tiles,
                      const float* proj_bias_padded, const float* gamma, const float* beta, float eps,
-                     const void* mlp_tiles, const float* b1_padded, const float* b2, void* stream);
+                     const void* mlp_tiles, const float* b1_padded, const float* b2, int nterms, void* stream);
 
 /* Window-resident attention block (csrc/win_attn_fused.hip): LayerNorm -> q/k/v projection -> softmax(q k^T + bias (+mask)) v
  * for ALL `nheads` heads of one 256-token window per workgroup; the qkv tensor never exists in memory.
@@ -134,7 +136,7 @@ int ff_win_attn_fused(const float* x, int ldx, float* out, int ldo, int o_off, c
  * (prep.pack_token_mlp); b1 zero padded to hidden_tiles*32; gamma/beta/w_tiles 16-byte aligned. */
 int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long long M, int K, int hidden_tiles, int N,
                  const float* gamma, const float* beta, float eps, const void* w_tiles, const float* b1_padded,
-                 const float* b2, void* stream);
+                 const float* b2, int nterms, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution with the input tile resident in LDS (csrc/conv3x3_halo.hip), bf16x3 MFMA:
  *   out = act(conv3x3(in) + bias) * mul[co] * alpha + res        (shuffle = 2: PixelShuffle(2) fused into the store)
@@ -151,7 +153,7 @@ long long ff_conv3x3_halo_pool_rows(int B, int H, int W, int Cout, int bn);
 int ff_pool_finish(const float* part, int rows, int ld, int C, float inv_count, float* out, void* stream);
 int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const float* bias, const float* mul,
                     const float* res, int ldr, float* out, int ldo, int B, int H, int W, int Cin, int Cout,
-                    int act, float alpha, int shuffle, float* pool_partials, void* stream);
+                    int act, float alpha, int shuffle, float* pool_partials, int nterms, void* stream);
 
 /* Token-stationary linear layer for K <= 192 (csrc/token_linear.hip), bf16x3 MFMA:
  *   out = res + res2*res2_scale[n] + act( LayerNorm?(x) . W^T + bias )        (gamma == NULL: no LayerNorm)
@@ -166,7 +168,7 @@ int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, i
                     const float* gamma, const float* beta, float eps, const void* w_tiles, const float* bias_padded,
                     int act, const float* res, int ldr, const float* res2, int ldr2, const float* res2_scale,
                     float* xn_out, int ldxn, float* stats_out, int stat_lo,
-                    int stat_hi, float stat_eps, void* stream);
+                    int stat_hi, float stat_eps, int nterms, void* stream);
 
 /* ff_token_linear with DAT's adaptive-interaction prologue (csrc/token_linear.hip, GATED): the GEMM input is
  *   x * cm[channel] + x2 * sm[token],   sm = sigmoid(gw2 . gelu(GW1 x + gb1) + gb2)
@@ -177,7 +179,7 @@ int ff_token_linear(const float* x, int ldx, float* out, int ldo, long long M, i
  * gb1 / gw2: [32] zero padded.  Replaces ff_pixel_mlp + ff_mix2 + ff_token_linear and the 47 MB tensor between them. */
 int ff_token_linear_gated(const float* x, int ldx, const float* x2, int ldx2, const float* cm, const float* gw1t, const float* gb1,
                           const float* gw2, float gb2, float* out, int ldo, long long M, int K, int N, int n_tiles,
-                          const void* w_tiles, const float* bias_padded, const float* res, int ldr, void* stream);
+                          const void* w_tiles, const float* bias_padded, const float* res, int ldr, int nterms, void* stream);
 
 /* NAFNet block fusions (csrc/naf_fused.hip).
  * ff_dwconv3_gate_pool: out[p][c] = dw3x3(in)[p][c] * dw3x3(in)[p][C + c] (conv2 + SimpleGate, nafnet_arch.py:78-81,51-52)
@@ -197,9 +199,9 @@ int ff_dwconv3_gate_pool(const float* in, int ldi, float* out, int ldo, int H, i
 long long ff_naf_front_workspace(int H, int W, int C);
 int ff_naf_front(const float* x, int ldx, int H, int W, int C, const float* ln_gamma, const float* ln_beta, float eps,
                  const void* w1_tiles, const float* b1, const float* dw_tapmajor, const float* dw_bias, float* out, int ldo,
-                 float* pooled, float* work, long long work_floats, void* stream);
+                 float* pooled, float* work, long long work_floats, int nterms, void* stream);
 int ff_naf_ffn(const float* y, int ldy, float* out, int ldo, long long M, int C, const float* gamma_ln, const float* beta_ln,
-               float eps, const void* w_tiles, const float* b4, const float* b5, const float* out_scale, void* stream);
+               float eps, const void* w_tiles, const float* b4, const float* b5, const float* out_scale, int nterms, void* stream);
 
 /* LayerNorm over the last axis of [rows][C] (nn.LayerNorm and NAFNet LayerNorm2d in NHWC):
  * hat_arch.py:272,307,397,437,964; dat_arch.py:117,734-735,931,1003; nafnet_arch.py:35-41. */
@@ -301,7 +303,7 @@ long long ff_chan_attn_workspace(long long N);
  * emits the block-diagonal [180][180] matrix of ff_chan_attn_weights (nblk = ceil(M / 256)). */
 long long ff_chan_qkv_workspace(long long M);
 int ff_chan_qkv(const float* x, int ldx, long long M, int K, const float* gamma, const float* beta, float eps, const void* w_tiles,
-                const float* bias_padded, float* v_out, int ldv, float* work, long long work_floats, void* stream);
+                const float* bias_padded, float* v_out, int ldv, float* work, long long work_floats, int nterms, void* stream);
 int ff_chan_attn_finish(float* work, long long work_floats, int nblk, const float* temperature, float* wbd, void* stream);
 
 /* Fusion-stack pointwise kernels (see csrc/fusion_ops.hip for the reference lines). */

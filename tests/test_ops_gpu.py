@@ -956,3 +956,95 @@ def test_conv3x3_small_matches_torch(dev, Cin, Cout, H, W, act, with_res):
         close(out, ref, 3e-6, "conv3x3 small")
     finally:
         ops.set_gemm_mode(prev)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Plain-bf16 forms (nterms = 1) of the fused kernels: BASELINE configs[1] names bf16.  One MFMA per product instead of three; results
+# are bf16-grade (operands rounded to 8 mantissa bits, fp32 accumulation).
+BF16_TOL = 1.5e-2     # relative to max|ref| for K <= 1620 contractions of O(1) operands
+
+
+def _both_modes(fn):
+    """fn() evaluated in 'bf16x3' and in 'bf16': -> (split result, plain result)."""
+    from isr2_amd import ops
+    prev = ops.gemm_mode()
+    try:
+        ops.set_gemm_mode("bf16x3")
+        a = fn()
+        ops.set_gemm_mode("bf16")
+        b = fn()
+    finally:
+        ops.set_gemm_mode(prev)
+    return a, b
+
+
+def test_plain_bf16_forms_of_the_fused_kernels(dev):
+    from isr2_amd import ops
+    from isr2_amd.prep import (pack_token_linear, pack_token_mlp, pack_token_projmlp, pack_chan_qkv, pack_token_linear_gated, pack_dw,
+                               pack_conv, pack_naf_ffn)
+    C, Hd, M = 180, 360, 3000
+    x = rnd(M, C, dev=dev, seed=1000, scale=1.5) + 0.3
+    g, b = rnd(C, dev=dev, seed=1001) * 0.1 + 1, rnd(C, dev=dev, seed=1002) * 0.1
+    w1, b1 = rnd(Hd, C, dev=dev, seed=1003, scale=1.0 / math.sqrt(C)), rnd(Hd, dev=dev, seed=1004, scale=0.1)
+    w2, b2 = rnd(C, Hd, dev=dev, seed=1005, scale=1.0 / math.sqrt(Hd)), rnd(C, dev=dev, seed=1006, scale=0.1)
+    wp, bp = rnd(C, C, dev=dev, seed=1007, scale=1.0 / math.sqrt(C)), rnd(C, dev=dev, seed=1008, scale=0.1)
+    att, res = rnd(M, C, dev=dev, seed=1009), rnd(M, C, dev=dev, seed=1010)
+
+    def check(name, pair, ref, tol=BF16_TOL):
+        s3, s1 = pair
+        close(s3, ref, 1e-4, name + " (bf16x3)")
+        close(s1, ref, tol, name + " (bf16)")
+        assert not torch.equal(s3, s1), name + ": the plain-bf16 form returned the split result (nterms not honoured?)"
+
+    # token_linear: LayerNorm + fc1 + GELU, and proj + residual
+    ref = F.gelu(F.linear(F.layer_norm(x, (C,), g, b, 1e-5), w1, b1))
+    check("token_linear ln+gelu", _both_modes(lambda: ops.token_linear(x, pack_token_linear(w1, b1), gamma=g, beta=b, act="gelu")), ref)
+    check("token_linear proj+res", _both_modes(lambda: ops.token_linear(att, pack_token_linear(wp, bp), res=res)), res + F.linear(att, wp, bp))
+    # token_mlp / token_projmlp
+    ref = x + F.linear(F.gelu(F.linear(F.layer_norm(x, (C,), g, b, 1e-5), w1, b1)), w2, b2)
+    check("token_mlp", _both_modes(lambda: ops.token_mlp(x, g, b, pack_token_mlp(w1, b1, w2, b2))), ref)
+    x1 = x + F.linear(att, wp, bp)
+    ref = x1 + F.linear(F.gelu(F.linear(F.layer_norm(x1, (C,), g, b, 1e-5), w1, b1)), w2, b2)
+    check("token_projmlp", _both_modes(lambda: ops.token_projmlp(att, x, pack_token_projmlp(wp, bp, w1, b1, w2, b2), g, b)), ref)
+    # gated projection (DAT)
+    cm = torch.sigmoid(rnd(C, dev=dev, seed=1011)).contiguous()
+    gw1, gb1, gw2 = rnd(11, C, dev=dev, seed=1012, scale=1.0 / math.sqrt(C)), rnd(11, dev=dev, seed=1013, scale=0.1), rnd(1, 11, dev=dev, seed=1014, scale=0.5)
+    sm = torch.sigmoid(F.linear(F.gelu(F.linear(x, gw1, gb1)), gw2) + 0.13)
+    ref = res + F.linear(x * cm + att * sm, wp, bp)
+    check("token_linear_gated", _both_modes(lambda: ops.token_linear_gated(x, att, pack_token_linear_gated(wp, bp, gw1, gb1, gw2), cm, 0.13, res=res)), ref)
+    # channel-attention front end: the v side output and the attention matrix
+    wqkv, bqkv = rnd(3 * C, C, dev=dev, seed=1015, scale=1.0 / math.sqrt(C)), rnd(3 * C, dev=dev, seed=1016, scale=0.1)
+    temp = (rnd(6, dev=dev, seed=1017) * 0.2 + 1.0).contiguous()
+    (v3, a3), (v1, a1) = _both_modes(lambda: ops.chan_qkv_attn(x, pack_chan_qkv(wqkv, bqkv), g, b, temp))
+    qkv = F.linear(F.layer_norm(x, (C,), g, b, 1e-5), wqkv, bqkv)
+    check("chan_qkv v", (v3, v1), qkv[:, 2 * C:])
+    close(a1, a3, 2e-2, "chan attention matrix bf16 vs bf16x3")
+    # LDS-resident 3x3 convolution
+    xc = rnd(1, 40, 48, 64, dev=dev, seed=1018)
+    wc, bc = rnd(60, 64, 3, 3, dev=dev, seed=1019, scale=1.0 / math.sqrt(576)), rnd(60, dev=dev, seed=1020, scale=0.1)
+    wpk = pack_conv(wc)
+    ref = F.gelu(F.conv2d(xc.permute(0, 3, 1, 2), wc, bc, padding=1)).permute(0, 2, 3, 1)
+    pair = _both_modes(lambda: ops.conv2d(xc, wpk, bc, ksize=(3, 3), pad=(1, 1), act="gelu"))
+    assert ops.PREPARED.peek(wpk, "halo") is not None
+    check("conv3x3 halo", pair, ref)
+    # NAFBlock halves
+    Cn = 64
+    xn_ = rnd(1, Cn, 40, 56, dev=dev, seed=1021, scale=1.5) + 0.2
+    gn, bn_ = rnd(Cn, dev=dev, seed=1022) * 0.1 + 1, rnd(Cn, dev=dev, seed=1023) * 0.1
+    nw1, nb1 = rnd(2 * Cn, Cn, dev=dev, seed=1024, scale=1.0 / math.sqrt(Cn)), rnd(2 * Cn, dev=dev, seed=1025, scale=0.1)
+    nw2, nb2 = rnd(2 * Cn, 1, 3, 3, dev=dev, seed=1026, scale=0.3), rnd(2 * Cn, dev=dev, seed=1027, scale=0.1)
+    mu = xn_.mean(1, keepdim=True)
+    ln = (xn_ - mu) / ((xn_ - mu).pow(2).mean(1, keepdim=True) + 1e-6).sqrt() * gn.view(1, -1, 1, 1) + bn_.view(1, -1, 1, 1)
+    t = F.conv2d(F.conv2d(ln, nw1.view(2 * Cn, Cn, 1, 1), nb1), nw2, nb2, padding=1, groups=2 * Cn)
+    ref = (t[:, :Cn] * t[:, Cn:]).permute(0, 2, 3, 1)
+    xh = xn_.permute(0, 2, 3, 1).contiguous()
+    (g3, p3), (g1, p1) = _both_modes(lambda: ops.naf_front(xh, pack_token_linear(nw1, nb1), gn, bn_, pack_dw(nw2), nb2))
+    check("naf_front", (g3, g1), ref, tol=3e-2)
+    w4, b4 = rnd(2 * Cn, Cn, dev=dev, seed=1028, scale=1.0 / math.sqrt(Cn)), rnd(2 * Cn, dev=dev, seed=1029, scale=0.1)
+    w5, b5 = rnd(Cn, Cn, dev=dev, seed=1030, scale=1.0 / math.sqrt(Cn)), rnd(Cn, dev=dev, seed=1031, scale=0.1)
+    gam = rnd(Cn, dev=dev, seed=1032) * 0.3
+    y = rnd(2000, Cn, dev=dev, seed=1033, scale=1.5) + 0.2
+    lny = F.layer_norm(y, (Cn,), gn, bn_, 1e-6)
+    h = F.linear(lny, w4, b4)
+    ref = y + gam * F.linear(h[:, :Cn] * h[:, Cn:], w5, b5)
+    check("naf_ffn", _both_modes(lambda: ops.naf_ffn(y, pack_naf_ffn(w4, b4, w5, b5), gn, bn_, gam)), ref, tol=3e-2)
