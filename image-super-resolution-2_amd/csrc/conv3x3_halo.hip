@@ -31,17 +31,28 @@ struct HaloParams {
 // WK = input channels per weight tile (64: one tile per (chunk, tap); 32: two).  The 192-channel configuration uses
 // 16x16-pixel workgroups (weights are re-streamed per workgroup: 256 pixels per fetch halve the L2 traffic that bounds
 // the 128-pixel form) and 32-channel weight tiles so that the 88 KB input tile and the ring still fit in 160 KB.
-// NTERMS = 3: split-bf16 products (fp32-grade); 1: plain bf16 (hi x hi only; the lo halves of the LDS rows are written but never read).
+// NTERMS = 3: split-bf16 products (fp32-grade).  NTERMS = 1: plain bf16 with a COMPACT LDS image -- pixel and weight rows hold the hi
+// plane only (64 k x 2 B + 16 B pad = 144 B: 36 dwords per row puts the 16 rows of a ds_read_b128 lane group on 16 distinct 4-bank
+// slots), halo-tile rows of 18 pixels are padded to 2816 B (== 0 mod 64 banks, as HX_PROW).  The 16x16-pixel tile then takes 50 KB
+// instead of 92 KB, so the 64-channel configurations run TWO workgroups per CU: one's input staging / epilogue overlaps the other's taps
+// (with one workgroup per CU those phases are serial: 35 us for the 12.7 GFLOP CAB convolutions against 7 us of MFMA time).
+template <int NTERMS> struct HaloGeom {
+  static constexpr int ROWB = NTERMS == 1 ? 144 : HX_ROW;          // bytes per pixel row in LDS
+  static constexpr int PROW = NTERMS == 1 ? 2816 : HX_PROW;        // bytes per halo-tile row of 18 pixels
+};
 template <int WM, int WN, int MI, int NI, int WK, int ACT, int NSLOT, int NTERMS>
-__global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (NTERMS == 1 && MI * NI <= 2 && WM * WN == 8) ? 4 : (NTERMS == 1 && MI * NI <= 2 && WM * WN == 4 && WM == 4) ? 3 : 1)
+void conv3x3_halo_kernel(HaloParams p) {
+  constexpr int ROWB = HaloGeom<NTERMS>::ROWB, PROW = HaloGeom<NTERMS>::PROW;
   constexpr int NW = WM * WN, NT = NW * 64;            // 4 or 8 waves
   static_assert(NW == 4 || NW == 8, "four or eight waves");
   constexpr int PPP = NT / 16;                         // pixels staged per pass (16 lanes per pixel)
   constexpr int TH = WM * MI * 2, NPX = (TH + 2) * HX_W, NPASS = (NPX + PPP - 1) / PPP;
   constexpr int BN = WN * NI * 32, TN = NI * 32;
-  constexpr int XBYTES = (TH + 2) * HX_PROW;
-  constexpr int WROW = WK * 4 + 16, NH = 64 / WK, KSTEPS = WK / 16;
-  constexpr bool XPREF = MI * NI <= 6;        // prefetch the next chunk's input rows into registers during tap 7
+  constexpr int XBYTES = (TH + 2) * PROW;
+  constexpr int WROW = (NTERMS == 1 ? WK * 2 : WK * 4) + 16, NH = 64 / WK, KSTEPS = WK / 16;
+  constexpr bool TWO_PER_CU = NTERMS == 1 && MI * NI <= 2 && WM * WN == 8;   // 128-register budget: the partner workgroup hides the chunk load instead
+  constexpr bool XPREF = MI * NI <= 6 && !TWO_PER_CU;   // prefetch the next chunk's input rows into registers during tap 7
   constexpr int WPIECES = (BN * WROW + 1023) / 1024, WSLOT = WPIECES * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Xs = smem;
@@ -117,9 +128,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
         lo[e] = (__bf16)(f - (float)h);
       }
       if (hp < NPX) {
-        unsigned char* dst = Xs + (hp / HX_W) * HX_PROW + (hp % HX_W) * HX_ROW + (tid & 15) * 8;
+        unsigned char* dst = Xs + (hp / HX_W) * PROW + (hp % HX_W) * ROWB + (tid & 15) * 8;
         *reinterpret_cast<bf16x4*>(dst) = hi;
-        *reinterpret_cast<bf16x4*>(dst + 128) = lo;
+        if (NTERMS == 3) *reinterpret_cast<bf16x4*>(dst + 128) = lo;
       }
     }
   };
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
   // per-lane LDS byte offsets (tap (0,0)): pixel row of m-tile i, weight row of n-tile j
   int aoff[MI], boff[NI];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) aoff[i] = ((wr * MI + i) * 2 + (l31 >> 4)) * HX_PROW + (l31 & 15) * HX_ROW + 16 * hh;
+  for (int i = 0; i < MI; ++i) aoff[i] = ((wr * MI + i) * 2 + (l31 >> 4)) * PROW + (l31 & 15) * ROWB + 16 * hh;
 #pragma unroll
   for (int j = 0; j < NI; ++j) boff[j] = (wc * TN + j * 32 + l31) * WROW + 16 * hh;
 
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap - 3 * dy;
-      const unsigned char* xa = Xs + dy * HX_PROW + dx * HX_ROW;
+      const unsigned char* xa = Xs + dy * PROW + dx * ROWB;
 #pragma unroll
       for (int half = 0; half < NH; ++half, ++T) {
         // own DMA pieces of tile T (and any prefetched input rows) have landed; the barrier then makes every wave's
@@ -168,12 +179,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             ah[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * (half * KSTEPS + s));
-            al[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * (half * KSTEPS + s) + 128);
+            if (NTERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * (half * KSTEPS + s) + 128);
           }
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
             bh[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s);
-            bl[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s + WK * 2);
+            if (NTERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s + WK * 2);
           }
 #pragma unroll
           for (int i = 0; i < MI; ++i)
@@ -273,8 +284,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(HaloParams p
 template <int WM, int WN, int MI, int NI, int WK, int NSLOT, int NTERMS>
 static int launch_halo(HaloParams& p, hipStream_t st) {
   constexpr int TH = WM * MI * 2, BN = WN * NI * 32;
-  constexpr int WSLOT = ((BN * (WK * 4 + 16) + 1023) / 1024) * 1024;
-  constexpr size_t lds = (size_t)(TH + 2) * HX_PROW + NSLOT * WSLOT;
+  constexpr int WSLOT = ((BN * ((NTERMS == 1 ? WK * 2 : WK * 4) + 16) + 1023) / 1024) * 1024;
+  constexpr size_t lds = (size_t)(TH + 2) * HaloGeom<NTERMS>::PROW + NSLOT * WSLOT;
   static_assert(lds <= 160 * 1024, "LDS budget");
   p.tiles_x = (p.W + 15) / 16;
   p.tiles_y = (p.H + TH - 1) / TH;
@@ -300,17 +311,29 @@ static int launch_halo(HaloParams& p, hipStream_t st) {
 }
 
 // bytes of the weight image prep.pack_conv3x3_halo must produce for (Cout, Cin, bn)
-extern "C" long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn) {
-  if (Cout <= 0 || Cin <= 0 || (bn != 32 && bn != 64 && bn != 128 && bn != 192)) return -1;
+extern "C" long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn, int nterms) {
+  if (Cout <= 0 || Cin <= 0 || (bn != 32 && bn != 64 && bn != 128 && bn != 192) || (nterms != 1 && nterms != 3)) return -1;
   const int wk = bn == 192 ? 32 : 64;                        // channels per weight tile (see launch_halo)
-  const long long slot = ((long long)bn * (wk * 4 + 16) + 1023) / 1024 * 1024;
+  const long long slot = ((long long)bn * ((nterms == 1 ? wk * 2 : wk * 4) + 16) + 1023) / 1024 * 1024;
   return (long long)((Cout + bn - 1) / bn) * ((Cin + 63) / 64) * 9 * (64 / wk) * slot;
 }
 
 // number of workgroups ( = rows of pool_partials, each nblk... see below) for (B, H, W, Cout, bn): rows x row length
-extern "C" long long ff_conv3x3_halo_pool_rows(int B, int H, int W, int Cout, int bn) {
-  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (bn != 32 && bn != 64 && bn != 128 && bn != 192)) return -1;
-  const int th = bn == 128 ? 8 : 16;                           // pixel rows per workgroup (launch table below)
+// pixel rows per workgroup (the launch table below).  Plain bf16, 32 / 64 output channels, and fewer than two 16x16 tiles per CU
+// (the 256x256 token grids of HAT / DAT: 256 tiles): 8-row tiles of four waves, 46 KB of LDS, up to three workgroups per CU -- with
+// one 16-row workgroup per CU the launch is as long as ONE workgroup's serial load / taps / store sequence.
+static int halo_rows_per_wg(int B, int H, int W, int Cout, int bn, int nterms) {
+  if (bn == 128) return 8;
+  if (nterms == 1 && bn <= 64) {
+    const long long tiles16 = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + bn - 1) / bn);
+    if (tiles16 < 512) return 8;
+  }
+  return 16;
+}
+
+extern "C" long long ff_conv3x3_halo_pool_rows(int B, int H, int W, int Cout, int bn, int nterms) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (bn != 32 && bn != 64 && bn != 128 && bn != 192) || (nterms != 1 && nterms != 3)) return -1;
+  const int th = halo_rows_per_wg(B, H, W, Cout, bn, nterms);
   return (long long)B * ((H + th - 1) / th) * ((W + 15) / 16) * ((Cout + bn - 1) / bn);
 }
 
@@ -332,6 +355,8 @@ extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int 
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.ldi = ldi; p.Cout = Cout; p.ldo = ldo; p.ldr = ldr;
   p.nchunk = (Cin + 63) / 64; p.act = act; p.alpha = alpha; p.shuffle = shuffle; p.pool_part = pool_partials;
   hipStream_t st = (hipStream_t)stream;
+  if (nterms == 1 && bn <= 64 && halo_rows_per_wg(B, H, W, Cout, bn, nterms) == 8)
+    return bn == 32 ? launch_halo<4, 1, 1, 1, 64, 2, 1>(p, st) : launch_halo<4, 1, 1, 2, 64, 2, 1>(p, st);   // 8x16 pixels, 4 waves
   switch (bn) {
     // 16x16-pixel workgroups of 8 waves (two per SIMD: one wave's LDS reads and waits hide behind the
     // other's MFMAs -- measured 140 -> 121 us for 180->180 against the 4-wave form)

@@ -365,13 +365,15 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
           and H * W >= 1024 and xp != op and B * H * W * ldi < 2 ** 31):
         from . import prep as _prep
 
+        nt_ = _nterms()
+
         def _mk_halo():
             bn = _prep.halo_bn(Cout)
-            return (_prep.pack_conv3x3_halo(w, Cin, bn), bn)
-        img = PREPARED.get(w, "halo", _mk_halo)
+            return (_prep.pack_conv3x3_halo(w, Cin, bn, nt_), bn)
+        img = PREPARED.get(w, "halo" if nt_ == 3 else "halo1", _mk_halo)
         part = None
         if want_pool and B == 1 and shuffle == 0 and Cout <= img[1]:
-            prow = int(_L().ff_conv3x3_halo_pool_rows(B, H, W, Cout, img[1]))
+            prow = int(_L().ff_conv3x3_halo_pool_rows(B, H, W, Cout, img[1], nt_))
             part = torch.empty((prow, img[1]), device=x.device, dtype=torch.float32)
         _lib.check(_L().ff_conv3x3_halo(xp, ldi, img[0].data_ptr(), img[1], _ptr(bias), _ptr(mul), rp, ldr, op, ldo, B, H, W,
                                         Cin, Cout, ACT[act], float(alpha), shuffle, _ptr(part), _nterms(), _stream()))

@@ -181,6 +181,12 @@ def export_plan(model, lr: torch.Tensor, stem: str, multi_stream: bool = True) -
         torch.cuda.synchronize(dev)
         found: Dict[int, Tuple[str, torch.Tensor]] = {}
         _walk_tensors(model, "model", found, set())
+        # the zero-padded concat / input buffers that outlive a forward (ops.persistent_zeros) are plan slots too: their untouched
+        # parts must be zero on the executor's side, exactly as here
+        from . import ops as _ops
+        for (owner, role, _dev), t in sorted(_ops._PERSIST_EAGER.items(), key=lambda kv: kv[0][1]):
+            if t.is_cuda and t.device == torch.device(dev) and t.data_ptr() not in found:
+                found[t.data_ptr()] = (f"persist.{role}.{'x'.join(str(v) for v in t.shape)}", t)
         real = _lib.load()
         rec = _Recorder(real, _lib.parse_header())
         slots = []                                                  # (name, storage ptr, nbytes)

@@ -79,10 +79,11 @@ def halo_bn(cout: int) -> int:
     return min((192, 128, 64), key=lambda bn: (-(-cout // bn) * bn, -bn))
 
 
-def pack_conv3x3_halo(wp: T, cin: int, bn: int) -> T:
+def pack_conv3x3_halo(wp: T, cin: int, bn: int, nterms: int = 3) -> T:
     """Weight image of ff_conv3x3_halo from a packed 3x3 weight [Cout, 9*cin] (tap-major, pack_conv):
     bf16 [nblk][nchunk][9][64/wk][bn rows x (wk hi | wk lo | 8 pad)], every record padded to 1 KiB; wk = channels per
-    weight tile = 32 for bn 192, 64 otherwise (csrc/conv3x3_halo.hip launch table)."""
+    weight tile = 32 for bn 192, 64 otherwise (csrc/conv3x3_halo.hip launch table).  nterms = 1 (plain bf16): compact rows
+    (wk hi | 8 pad) -- the kernel's LDS image then holds no lo plane."""
     cout = wp.shape[0]
     assert wp.shape[1] == 9 * cin
     wk = 32 if bn == 192 else 64
@@ -92,10 +93,12 @@ def pack_conv3x3_halo(wp: T, cin: int, bn: int) -> T:
     w[:cout, :, :cin] = wp.reshape(cout, 9, cin)
     hi = w.to(torch.bfloat16)
     lo = (w - hi.float()).to(torch.bfloat16)
-    rows = torch.zeros(nblk, nchunk, 9, nh, bn, 2 * wk + 8, device=wp.device, dtype=torch.bfloat16)
+    rw = (2 * wk if nterms == 3 else wk) + 8
+    rows = torch.zeros(nblk, nchunk, 9, nh, bn, rw, device=wp.device, dtype=torch.bfloat16)
     rows[..., :wk] = hi.reshape(nblk, bn, 9, nchunk, nh, wk).permute(0, 3, 2, 4, 1, 5)
-    rows[..., wk:2 * wk] = lo.reshape(nblk, bn, 9, nchunk, nh, wk).permute(0, 3, 2, 4, 1, 5)
-    rec = bn * (2 * wk + 8)
+    if nterms == 3:
+        rows[..., wk:2 * wk] = lo.reshape(nblk, bn, 9, nchunk, nh, wk).permute(0, 3, 2, 4, 1, 5)
+    rec = bn * rw
     slot = (rec * 2 + 1023) // 1024 * 1024
     img = torch.zeros(nblk * nchunk * 9 * nh, slot // 2, device=wp.device, dtype=torch.bfloat16)
     img[:, :rec] = rows.reshape(nblk * nchunk * 9 * nh, rec)

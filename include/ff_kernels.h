@@ -144,12 +144,13 @@ int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long long M, int 
  * once per 64-channel chunk instead of once per filter tap.  Replaces nn.Conv2d(k=3, s=1, p=1) of hat_arch.py:121-130
  * (CAB), :768, :921-953; dat_arch.py:396,772; nafnet_arch.py:187,193 and the fusion stack's 3x3 convolutions.
  * bn in {32, 64, 128, 192} = output channels per workgroup.  w_img: prep.pack_conv3x3_halo image
- * [ceil(Cout/bn)][ceil(Cin/64)][9 taps][bn rows x (64 hi | 64 lo | 8 pad) bf16, padded to 1 KiB], of
- * ff_conv3x3_halo_weight_bytes(Cout, Cin, bn) bytes (-1: bad arguments).  Needs Cin % 4 == 0, 16-byte aligned rows. */
-long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn);
-/* pool_partials (optional, Cout <= bn, no shuffle): [ff_conv3x3_halo_pool_rows(B,H,W,Cout,bn)][bn] per-workgroup channel sums of the
+ * [ceil(Cout/bn)][ceil(Cin/64)][9 taps][bn rows x (64 hi | 64 lo | 8 pad) bf16, padded to 1 KiB] for nterms = 3, and the compact
+ * hi-only rows (64 hi | 8 pad) for nterms = 1 (then the 16x16-pixel tile is 50 KB of LDS and the 64-channel forms run two
+ * workgroups per CU), of ff_conv3x3_halo_weight_bytes(Cout, Cin, bn, nterms) bytes (-1: bad arguments).  Needs Cin % 4 == 0, 16-byte aligned rows. */
+long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn, int nterms);
+/* pool_partials (optional, Cout <= bn, no shuffle): [ff_conv3x3_halo_pool_rows(B,H,W,Cout,bn,nterms)][bn] per-workgroup channel sums of the
  * stored output, finished by ff_pool_finish (the global average pool of hat_arch.py:50 without re-reading the tensor). */
-long long ff_conv3x3_halo_pool_rows(int B, int H, int W, int Cout, int bn);
+long long ff_conv3x3_halo_pool_rows(int B, int H, int W, int Cout, int bn, int nterms);
 int ff_pool_finish(const float* part, int rows, int ld, int C, float inv_count, float* out, void* stream);
 int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const float* bias, const float* mul,
                     const float* res, int ldr, float* out, int ldo, int B, int H, int W, int Cin, int Cout,

@@ -1025,8 +1025,15 @@ def test_plain_bf16_forms_of_the_fused_kernels(dev):
     wpk = pack_conv(wc)
     ref = F.gelu(F.conv2d(xc.permute(0, 3, 1, 2), wc, bc, padding=1)).permute(0, 2, 3, 1)
     pair = _both_modes(lambda: ops.conv2d(xc, wpk, bc, ksize=(3, 3), pad=(1, 1), act="gelu"))
-    assert ops.PREPARED.peek(wpk, "halo") is not None
+    assert ops.PREPARED.peek(wpk, "halo") is not None and ops.PREPARED.peek(wpk, "halo1") is not None     # both weight images were built
     check("conv3x3 halo", pair, ref)
+    for ci_, co_, hw_ in ((180, 60, (37, 45)), (60, 180, (40, 33)), (180, 180, (33, 20)), (76, 64, (64, 70)), (64, 32, (50, 40))):   # ragged tiles, every launch form
+        xq = rnd(1, hw_[0], hw_[1], ci_, dev=dev, seed=1040 + ci_)
+        wq, bq = rnd(co_, ci_, 3, 3, dev=dev, seed=1041 + co_, scale=1.0 / math.sqrt(9 * ci_)), rnd(co_, dev=dev, seed=1042, scale=0.1)
+        wqp = pack_conv(wq)
+        rq = rnd(1, hw_[0], hw_[1], co_, dev=dev, seed=1043)
+        refq = rq + F.conv2d(xq.permute(0, 3, 1, 2), wq, bq, padding=1).permute(0, 2, 3, 1)
+        check(f"conv3x3 halo {ci_}->{co_}", _both_modes(lambda: ops.conv2d(xq, wqp, bq, ksize=(3, 3), pad=(1, 1), res=rq)), refq)
     # NAFBlock halves
     Cn = 64
     xn_ = rnd(1, Cn, 40, 56, dev=dev, seed=1021, scale=1.5) + 0.2
