@@ -26,6 +26,28 @@ def per_kernel(d, counter):
     return agg
 
 
+def product_kernel_names():
+    """Names of the __global__ kernels this library defines (csrc/): everything else in a trace -- ATen element-wise / copy kernels of
+    the weight preparation at model build, the runtime's buffer copies, rocBLAS -- is SETUP, not part of a forward."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "image-super-resolution-2_amd", "csrc")
+    names = set()
+    for f in os.listdir(d):
+        txt = open(os.path.join(d, f)).read()
+        names.update(re.findall(r"__global__[^;{]*?\bvoid\s+(\w+)\s*\(", txt))
+    return names
+
+
+SETUP_ONLY = {"split_bf16_kernel"}          # ours, but launched by the weight preparation at load (static weights), not per forward
+
+
+def is_product(kernel_name: str, names) -> bool:
+    base = kernel_name.replace("void ", "").split("<")[0].split("(")[0].strip()
+    return base in names and base not in SETUP_ONLY
+
+
 def main():
     fdir, wdir, out = sys.argv[1:4]
     fe, wr = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
@@ -54,6 +76,9 @@ def main():
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     forwards = sum(v["calls"] for k, v in kernels.items() if "fuse_blend" in k)      # launched exactly once per forward
+    names = product_kernel_names()
+    for k, v in kernels.items():
+        v["product"] = is_product(k, names)
     doc = {"note": __doc__.split("\n\n")[-1].replace("\n", " "), "csrc_fingerprint": h.hexdigest()[:16], "forwards": forwards,
            "git": os.environ.get("FF_GIT_HASH", "n/a"), "kernels": kernels,
            "conv_igemm_all_variants": family(lambda k: "conv_igemm" in k or "conv3x3_halo" in k),
@@ -62,10 +87,14 @@ def main():
            "win_attn_fused_all_variants": family(lambda k: "win_attn_fused" in k),
            "token_mlp": family(lambda k: "token_mlp" in k),
            "token_projmlp": family(lambda k: "token_projmlp" in k),
-           "whole_forward": family(lambda k: True)}
+           "whole_forward": family(lambda k: kernels[k]["product"]),
+           "setup_and_runtime": family(lambda k: not kernels[k]["product"]),
+           "whole_forward_note": "whole_forward sums ONLY this library's kernels (csrc/ __global__ names); setup_and_runtime holds the ATen "
+                                 "element-wise / copy kernels of the weight preparation at model build, runtime buffer copies and ff_split_bf16 "
+                                 "(static weight planes), which run once per model, not per forward"}
     json.dump(doc, open(out, "w"), indent=1)
     for k in ("conv_igemm_all_variants", "token_linear_all_variants", "window_attn_all_variants", "win_attn_fused_all_variants", "token_mlp",
-              "token_projmlp", "whole_forward"):
+              "token_projmlp", "whole_forward", "setup_and_runtime"):
         print(k, doc[k])
 
 
