@@ -10,6 +10,7 @@
 // previous tap.  Accumulators stay in registers over all chunks and taps (K = 9*Cin).
 //   LDS row (pixel or weight row) = [64 k hi | 64 k lo | 16 B pad] = 272 B = 68 dwords: conflict-free ds_read_b128.
 #include "ff_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -36,6 +37,23 @@ struct HaloParams {
 // slots), halo-tile rows of 18 pixels are padded to 2816 B (== 0 mod 64 banks, as HX_PROW).  The 16x16-pixel tile then takes 50 KB
 // instead of 92 KB, so the 64-channel configurations run TWO workgroups per CU: one's input staging / epilogue overlaps the other's taps
 // (with one workgroup per CU those phases are serial: 35 us for the 12.7 GFLOP CAB convolutions against 7 us of MFMA time).
+template <int N> __device__ __forceinline__ void halo_wait_vmcnt() {
+  static_assert(N >= 0 && N <= 12, "counted vmcnt out of range");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
 template <int NTERMS> struct HaloGeom {
   static constexpr int ROWB = NTERMS == 1 ? 144 : HX_ROW;          // bytes per pixel row in LDS
   static constexpr int PROW = NTERMS == 1 ? 2816 : HX_PROW;        // bytes per halo-tile row of 18 pixels
@@ -85,13 +103,17 @@ void conv3x3_halo_kernel(HaloParams p) {
     }
   };
   const int ntiles = p.nchunk * 9 * NH;
-  // Ring depth: NSLOT = 3 issues the tile for tap T+2 while tap T computes and lets the (younger) pieces of tile T+1 stay in flight
-  // at the top of tap T (s_waitcnt vmcnt(NPMIN), NPMIN = the fewest pieces any wave issues per tile; over-waiting by one piece on the
-  // other waves is safe: vmcnt retires in issue order).  Measured in round 2: no gain over two slots (CAB 180->60: 54.5 vs 53.2 us; the
-  // weight tiles are L2 hits that land within a tap's MFMAs) and slower for the 32-channel form, so every configuration launches NSLOT = 2.
+  // Ring of NSLOT weight slots, DEPTH = NSLOT - 1 tiles in flight: tile T + DEPTH is issued at the top of tile T (into the slot tile T - 1
+  // just vacated) and waited for DEPTH tiles later with a COUNTED s_waitcnt vmcnt(NPMIN * (DEPTH - 1)) (NPMIN = the fewest pieces any wave
+  // issues per tile; waves that issue one more over-wait by a piece: vmcnt retires in issue order) followed by a RAW s_barrier.
+  // __syncthreads() would not do: with an LDS-DMA outstanding its fence waits vmcnt(0) and drains the ring (round 2 measured "no gain"
+  // from three slots for exactly that reason).  With one tile in flight (NSLOT = 2) every tap exposes the L2 latency of its weight tile
+  // (~0.7 us against 0.12 us of MFMA work per tap in plain bf16).
+  constexpr int DEPTH = NSLOT - 1;
   constexpr int NPMIN = WPIECES / NW;
-  dma(0, 0);
-  if (NSLOT > 2 && ntiles > 1) dma(1, 1);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (d < ntiles) dma(d, d);
 
   // ---- input halo staging: 16 lanes (float4 each) per pixel, 16 pixels per pass ---------------------------------
   const int cq = (tid & 15) * 4, prow = tid >> 4;
@@ -159,18 +181,14 @@ void conv3x3_halo_kernel(HaloParams p) {
       const unsigned char* xa = Xs + dy * PROW + dx * ROWB;
 #pragma unroll
       for (int half = 0; half < NH; ++half, ++T) {
-        // own DMA pieces of tile T (and any prefetched input rows) have landed; the barrier then makes every wave's
-        // pieces and the staged input tile visible, and guarantees slot (T+1)&1 is no longer being read
-        if (NSLOT > 2 && NPMIN > 0 && T + 1 < ntiles) {
-          if (NPMIN == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-          else if (NPMIN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        if (NSLOT > 2) { if (T + 2 < ntiles) dma(T + 2, (T + 2) % NSLOT); }
-        else if (T + 1 < ntiles) dma(T + 1, (T + 1) & 1);
+        // own DMA pieces of tile T have landed (counted wait: the younger tiles stay in flight); LDS writes of this wave (the staged
+        // input tile) are complete; the barrier then makes every wave's pieces and the input tile visible, and guarantees the slot of
+        // tile T - 1 is no longer being read
+        if (T + DEPTH - 1 < ntiles) halo_wait_vmcnt<NPMIN * (DEPTH - 1)>();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (T + DEPTH < ntiles) dma(T + DEPTH, (T + DEPTH) % NSLOT);
         if (XPREF && tap == 7 && half == NH - 1 && chunk + 1 < p.nchunk) load_x(chunk + 1);
         const unsigned char* wb = Ws + (T % NSLOT) * WSLOT;
 #pragma unroll
@@ -355,8 +373,16 @@ extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int 
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.ldi = ldi; p.Cout = Cout; p.ldo = ldo; p.ldr = ldr;
   p.nchunk = (Cin + 63) / 64; p.act = act; p.alpha = alpha; p.shuffle = shuffle; p.pool_part = pool_partials;
   hipStream_t st = (hipStream_t)stream;
-  if (nterms == 1 && bn <= 64 && halo_rows_per_wg(B, H, W, Cout, bn, nterms) == 8)
-    return bn == 32 ? launch_halo<4, 1, 1, 1, 64, 2, 1>(p, st) : launch_halo<4, 1, 1, 2, 64, 2, 1>(p, st);   // 8x16 pixels, 4 waves
+  static const int ring = []() { const char* e = getenv("FF_HALO_RING"); return e ? atoi(e) : 0; }();   // tuning switch: weight-ring slots
+  if (nterms == 1 && bn <= 64 && halo_rows_per_wg(B, H, W, Cout, bn, nterms) == 8) {   // 8x16 pixels, 4 waves
+    if (bn == 32) return launch_halo<4, 1, 1, 1, 64, 2, 1>(p, st);
+    if (ring == 3) return launch_halo<4, 1, 1, 2, 64, 3, 1>(p, st);
+    if (ring == 4) return launch_halo<4, 1, 1, 2, 64, 4, 1>(p, st);
+    if (ring == 5) return launch_halo<4, 1, 1, 2, 64, 5, 1>(p, st);
+    return launch_halo<4, 1, 1, 2, 64, 2, 1>(p, st);
+  }
+  if (nterms == 1 && bn == 64 && ring == 3) return launch_halo<8, 1, 1, 2, 64, 3, 1>(p, st);
+  if (nterms == 1 && bn == 192 && ring >= 3) return launch_halo<4, 2, 2, 3, 32, 3, 1>(p, st);
   switch (bn) {
     // 16x16-pixel workgroups of 8 waves (two per SIMD: one wave's LDS reads and waits hide behind the
     // other's MFMAs -- measured 140 -> 121 us for 180->180 against the 4-wave form)
