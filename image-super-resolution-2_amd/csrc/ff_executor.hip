@@ -87,6 +87,8 @@ extern "C" int ff_create(const char* plan_path, void** out_handle) {
     if (fid == 0xFFFF) { c.fn = -1; c.first = 0; c.n = 0; c.stream = sid; if (sid > 1) return fail("bad marker"); continue; }
     if (fid >= nnames || na > 64 || sid > 2) return fail("bad call record");
     c.fn = fnmap[fid]; c.first = (int)m->args.size(); c.n = na; c.stream = sid;
+    const char* kinds = FF_DISPATCH_KINDS[c.fn];
+    if ((size_t)na != strlen(kinds)) { ff_set_error("ff_create: %s: a call of %s carries %d arguments, the entry point takes %zu", plan_path, FF_DISPATCH_NAMES[c.fn], (int)na, strlen(kinds)); fclose(f); free_model(m); return FF_ERR_ARG; }
     if (sid + 1 > m->nstreams) m->nstreams = sid + 1;
     for (int i = 0; i < na; ++i) {
       unsigned char rec[20];
@@ -97,6 +99,15 @@ extern "C" int ff_create(const char* plan_path, void** out_handle) {
       if (a.kind > K_STREAM) return fail("bad argument kind");
       if (a.kind == K_WEIGHT && (a.a < 0 || a.a >= (long long)nslots || a.b < 0 || a.b >= m->slots[a.a].nbytes)) return fail("weight reference out of range");
       if (a.kind == K_WORK && (a.b < 0 || a.b >= m->wbytes)) return fail("workspace reference out of range");
+      {
+        const long long in_bytes = 4LL * m->in[0] * m->in[1] * m->in[2] * m->in[3], out_bytes = 4LL * m->out[0] * m->out[1] * m->out[2] * m->out[3];
+        if (a.kind == K_INPUT && (a.b < 0 || a.b >= in_bytes)) return fail("input reference beyond the lr tensor");
+        if (a.kind == K_OUTPUT && (a.b < 0 || a.b >= out_bytes)) return fail("output reference beyond the sr tensor");
+        const char want = kinds[i];
+        const bool ok = want == 'P' ? (a.kind == K_NULL || a.kind == K_WEIGHT || a.kind == K_WORK || a.kind == K_INPUT || a.kind == K_OUTPUT)
+                       : want == 'I' ? a.kind == K_INT : want == 'F' ? a.kind == K_FLT : a.kind == K_STREAM;
+        if (!ok) { ff_set_error("ff_create: %s: argument %d of %s has kind %d where the prototype has '%c'", plan_path, i, FF_DISPATCH_NAMES[c.fn], (int)a.kind, want); fclose(f); free_model(m); return FF_ERR_ARG; }
+      }
       m->args.push_back(a);
     }
   }

@@ -168,7 +168,7 @@ def _pack_offsets(work: List[list], regions: List[Tuple[int, int]] = ()) -> Tupl
 
 
 @torch.no_grad()
-def export_plan(model, lr: torch.Tensor, stem: str, multi_stream: bool = True) -> dict:
+def export_plan(model, lr: torch.Tensor, stem: str, multi_stream: bool = True, verify: bool = True) -> dict:
     """Record model.forward(lr) and write <stem>.ffplan / <stem>.ffwts.  multi_stream: keep the host's three-stream schedule
     (the experts side by side between a fork and a join marker; the executor replays them on two internal streams).
     Returns a summary dict."""
@@ -201,14 +201,18 @@ def export_plan(model, lr: torch.Tensor, stem: str, multi_stream: bool = True) -
 
         orig = {n: getattr(torch, n) for n in ("empty", "empty_like", "zeros", "zeros_like")}
 
-        def hook(fn):
+        def hook(fn, zeroing):
             def f(*a, **k):
                 t = fn(*a, **k)
+                if zeroing and isinstance(t, torch.Tensor) and t.is_cuda:
+                    # a buffer zeroed DURING a forward is a memset the tape does not carry: the replay would read stale bytes
+                    raise _lib.FFError("plan recording: the forward zero-fills a device buffer per call (torch.zeros / zeros_like inside the "
+                                       "recorded pass); make it a persistent buffer (ops.persistent_zeros) or an ff_* fill")
                 rec.note_alloc(t)
                 return t
             return f
         for n, fn in orig.items():
-            setattr(torch, n, hook(fn))
+            setattr(torch, n, hook(fn, n.startswith("zeros")))
         _lib._lib = rec
         model._marker = rec.mark
         rec.streams[int(torch.cuda.current_stream(dev).cuda_stream)] = 0
@@ -297,6 +301,20 @@ def export_plan(model, lr: torch.Tensor, stem: str, multi_stream: bool = True) -
             b = path.encode()
             f.write(struct.pack("<I", len(b)) + b + struct.pack("<q", nbytes))
             f.write(raw.cpu().numpy().tobytes())
+    # Self-check of the WRITTEN files: the recording pass above still ran every host-side op, so it cannot show that
+    # the tape alone reproduces the forward.  Load the plan through the executor and replay it twice -- the second time on a
+    # workspace the first one left dirty -- and require the recorded forward's result, bit for bit.
+    if verify:
+        nat = NativeModel(stem + ".ffplan", stem + ".ffwts")
+        try:
+            for rep in range(2):
+                got = nat(lr)
+                torch.cuda.synchronize(dev)
+                if not torch.equal(got, ref):
+                    raise _lib.FFError(f"plan self-check: replay {rep + 1} of the written plan differs from the recorded forward "
+                                       f"(max |d| = {float((got - ref).abs().max()):.3e}): a buffer or a copy the tape does not carry")
+        finally:
+            nat.close()
     return {"calls": sum(1 for n, _, _ in rec.calls if n not in ("fork", "join")), "streams": nstreams, "entry_points": len(names), "slots": len(used_slots),
             "weight_bytes": sum(slots[s][2] for s in used_slots), "workspace_bytes": wbytes,
             "activation_bytes_unpacked": sum(w[0] for w in rec.work if w[1] >= 0), "in_shape": tuple(lr.shape), "out_shape": tuple(out.shape)}

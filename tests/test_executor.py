@@ -64,6 +64,31 @@ def test_create_rejects_bad_plans(tmp_path):
     assert L.ff_forward(None, None, 1, 1, 1, None, None) != 0     # null handle is an error, not a crash
     assert L.ff_destroy(None) == 0
 
+    # a structurally valid plan whose ONE call does not fit the entry point's prototype: rejected before anything is
+    # allocated or launched -- wrong arity, a float where a pointer belongs, an input offset beyond the lr tensor
+    K_INT, K_FLT, K_NULL, K_WEIGHT, K_WORK, K_INPUT, K_OUTPUT, K_STREAM = range(8)
+    proto = lib.parse_header()["ff_avgpool2"][1]                 # (const float* in, int ldi, float* out, int ldo, int B, int H, int W, int C, void* stream)
+    assert len(proto) == 9
+
+    def arg(kind, a=0, b=0, f=None):
+        return struct.pack("<B3x", kind) + (struct.pack("<d8x", f) if f is not None else struct.pack("<qq", a, b))
+
+    def plan_with(args):
+        blob = b"FFPLAN3\0" + struct.pack("<iI", L.ff_abi_version(), 1) + struct.pack("<I", 11) + b"ff_avgpool2"
+        blob += struct.pack("<I", 0)                                           # no weight slots
+        blob += struct.pack("<q4i4i", 1 << 20, 1, 3, 8, 8, 1, 3, 32, 32)       # workspace bytes, in / out shapes
+        blob += struct.pack("<I", 1) + struct.pack("<HHH", 0, len(args), 0) + b"".join(args)
+        return blob
+    good = [arg(K_INPUT, 0, 0), arg(K_INT, 3), arg(K_WORK, 0, 0), arg(K_INT, 3), arg(K_INT, 1), arg(K_INT, 8), arg(K_INT, 8), arg(K_INT, 3), arg(K_STREAM)]
+    cases = {"arity": good[:-2] + [good[-1]], "kind": [arg(K_FLT, f=1.0)] + good[1:], "input offset": [arg(K_INPUT, 0, 4 * 3 * 8 * 8)] + good[1:],
+             "output offset": good[:2] + [arg(K_OUTPUT, 0, 4 * 3 * 32 * 32 + 4)] + good[3:], "stream kind": good[:-1] + [arg(K_INT, 0)]}
+    for what, args in cases.items():
+        p = tmp_path / "bad_call.ffplan"
+        p.write_bytes(plan_with(args))
+        assert L.ff_create(str(p).encode(), ctypes.byref(h)) != 0 and not h.value, what
+        err = L.ff_last_error()
+        assert (b"argument" in err or b"reference" in err), (what, err)
+
 
 @pytest.mark.gpu
 def test_native_executor_replays_the_python_forward_bit_for_bit(tmp_path, synth_sd):
