@@ -51,6 +51,9 @@ def _tl(blk: dict, key: str) -> dict:
     return pk
 
 
+_CAB_FUSED = os.environ.get("FF_CAB_FUSED", "0") == "1"        # opt-in: HAT's conv branch in one launch (csrc/cab_fused.hip); bit-identical to the two launches, measured no faster
+
+
 def _fast() -> bool:
     """The token-stationary fused kernels exist for the default split-bf16 contraction only."""
     return ops.fused_modes()
@@ -191,8 +194,11 @@ class HatHIP:
             ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
                             kwin=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, heads=self.heads, d=d, scale=d ** -0.5,
                             rel_table=blk["rel"] if _REL_BIAS else None)
-        c1 = ops.conv2d(xn, *blk["cab0"], ksize=(3, 3), pad=(1, 1), act="gelu")
-        c2, c2mean = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1), want_pool=True)   # pool from the conv epilogue
+        if _CAB_FUSED and ops.gemm_mode() == "bf16" and blk["cab0"][0].shape[0] <= 64 and C <= 192 and x.shape[0] == 1:
+            c2, c2mean = ops.cab_fused(xn, blk["cab0"][0], blk["cab0"][1], blk["cab2"][0], blk["cab2"][1])    # conv -> GELU -> conv + pool, one launch
+        else:
+            c1 = ops.conv2d(xn, *blk["cab0"], ksize=(3, 3), pad=(1, 1), act="gelu")
+            c2, c2mean = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1), want_pool=True)   # pool from the conv epilogue
         gate = ops.vec_mlp(c2mean, *blk["ca1"], "relu", *blk["ca2"], "sigmoid", post=self.conv_scale)
         if _fast() and _PROJ_MLP:                                  # proj + both residuals + norm2 + MLP: x1 never reaches memory
             return ops.token_projmlp(att, x, _pm(blk), blk["n2"][0], blk["n2"][1], c2=c2, c2_scale=gate.reshape(-1))

@@ -395,6 +395,30 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
     return out
 
 
+def cab_fused(x: T, w1: T, b1: T, w2: T, b2: T):
+    """HAT's CAB in one launch (plain bf16 only): conv3x3(x, w1) + b1 -> GELU -> conv3x3(., w2) + b2 and the global average pool of the
+    result.  x [1,H,W,Cin] rows view, w1 / w2 packed [Cmid, 9*Cin] / [Cout, 9*Cmid] -> (out [1,H,W,Cout], pooled [1,Cout])."""
+    if _GEMM_MODE != "bf16":
+        raise _lib.FFError("cab_fused exists for the plain-bf16 contraction mode only")
+    xp, ldi, B, H, W, Cin = _nhwc(x, "cab_fused.x")
+    Cmid, Cout = w1.shape[0], w2.shape[0]
+    if B != 1 or w1.shape[1] != 9 * Cin or w2.shape[1] != 9 * Cmid:
+        raise _lib.FFError("cab_fused: expects one image and packed 3x3 weights [Cmid, 9*Cin], [Cout, 9*Cmid]")
+    from . import prep as _prep
+    i1 = PREPARED.get(w1, "cab1", lambda: _prep.pack_conv3x3_halo(w1, Cin, 64, 1))
+    i2 = PREPARED.get(w2, "cab2", lambda: _prep.pack_conv3x3_halo(w2, Cmid, 192, 1))
+    out = empty_rows((1, H, W, Cout), x.device)
+    op, ldo, *_ = _nhwc(out, "cab_fused.out")
+    prow = int(_L().ff_cab_fused_pool_rows(H, W))
+    part = torch.empty((prow, 192), device=x.device, dtype=torch.float32)
+    pooled = torch.empty((1, Cout), device=x.device, dtype=torch.float32)
+    _lib.check(_L().ff_cab_fused(xp, ldi, i1.data_ptr(), b1.data_ptr(), i2.data_ptr(), b2.data_ptr(), op, ldo, H, W, Cin, Cmid, Cout,
+                                 part.data_ptr(), _stream()))
+    _lib.check(_L().ff_pool_finish(part.data_ptr(), prow, 192, Cout, 1.0 / float(H * W), pooled.data_ptr(), _stream()))
+    _note(2.0 * H * W * 9 * (Cmid * Cin + Cout * Cmid), 4.0 * H * W * (Cin + Cout))
+    return out, pooled
+
+
 def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] = None, mul: Optional[T] = None,
            alpha: float = 1.0, out: Optional[T] = None, dynamic_w: bool = False, kmul: Optional[T] = None,
            gate_pairs: bool = False) -> T:
@@ -1019,7 +1043,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "linear", "win_attn_fused", "token_projmlp", "token_linear_gated", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_front", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
+for _n in ("conv2d", "cab_fused", "linear", "win_attn_fused", "token_projmlp", "token_linear_gated", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_front", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights", "chan_qkv_attn",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

@@ -74,6 +74,10 @@ def quad_bias(biasT: T) -> T:
 
 def halo_bn(cout: int) -> int:
     """Output channels per workgroup of ff_conv3x3_halo: least padding, ties to the wider tile."""
+    import os
+    force = os.environ.get("FF_HALO_BN")                      # tuning switch: "32" / "64" force narrower output blocks
+    if force and int(force) in (32, 64) and cout > int(force):
+        return int(force)
     if cout <= 32:
         return 32
     return min((192, 128, 64), key=lambda bn: (-(-cout // bn) * bn, -bn))

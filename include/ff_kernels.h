@@ -156,6 +156,16 @@ int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const f
                     const float* res, int ldr, float* out, int ldo, int B, int H, int W, int Cin, int Cout,
                     int act, float alpha, int shuffle, float* pool_partials, int nterms, void* stream);
 
+/* HAT's convolution branch in one launch, plain bf16 (csrc/cab_fused.hip; hat_arch.py:61-74 CAB = conv3x3 Cin -> Cmid, GELU,
+ * conv3x3 Cmid -> Cout, and the per-workgroup channel sums of the result for ChannelAttention's global average pool, :50):
+ *   out = conv2(GELU(conv1(in) + b1)) + b2,   pool_partials [ff_cab_fused_pool_rows(H, W)][192] (finish with ff_pool_finish, ld 192)
+ * The first convolution is evaluated on the 18x18 halo of every 16x16 output tile and kept in LDS as the bf16 operand of the second:
+ * bit-identical to two ff_conv3x3_halo(nterms = 1) launches, without the Cmid-channel tensor and one launch.  w1_img / w2_img:
+ * prep.pack_conv3x3_halo(w1, Cin, 64, 1) / (w2, Cmid, 192, 1).  B = 1; Cmid <= 64, Cout <= 192, Cin % 4 == 0. */
+long long ff_cab_fused_pool_rows(int H, int W);
+int ff_cab_fused(const float* in, int ldi, const void* w1_img, const float* b1, const void* w2_img, const float* b2, float* out, int ldo,
+                 int H, int W, int Cin, int Cmid, int Cout, float* pool_partials, void* stream);
+
 /* Token-stationary linear layer for K <= 192 (csrc/token_linear.hip), bf16x3 MFMA:
  *   out = res + res2*res2_scale[n] + act( LayerNorm?(x) . W^T + bias )        (gamma == NULL: no LayerNorm)
  * x is read once and kept in registers, W streams through LDS by DMA.  Replaces nn.LayerNorm + nn.Linear (+GELU,

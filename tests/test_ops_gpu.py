@@ -1055,3 +1055,31 @@ def test_plain_bf16_forms_of_the_fused_kernels(dev):
     h = F.linear(lny, w4, b4)
     ref = y + gam * F.linear(h[:, :Cn] * h[:, Cn:], w5, b5)
     check("naf_ffn", _both_modes(lambda: ops.naf_ffn(y, pack_naf_ffn(w4, b4, w5, b5), gn, bn_, gam)), ref, tol=3e-2)
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (48, 64), (37, 45), (33, 32), (40, 100)])
+def test_cab_fused_equals_the_two_launch_path(dev, H, W):
+    """HAT's CAB in one launch (csrc/cab_fused.hip, plain bf16): conv3x3 180 -> 60, GELU, conv3x3 60 -> 180 and the average pool,
+    bit-identical to the two LDS-resident 3x3 launches it replaces (same K order, same rounding points), incl. ragged tiles -- the
+    first convolution's values OUTSIDE the image must be the second one's zero padding, not conv1 of padded input."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_conv
+    C, Cm = 180, 60
+    prev = ops.gemm_mode()
+    ops.set_gemm_mode("bf16")
+    try:
+        x = torch.empty(1, H, W, 192, device=dev)[..., :C]
+        x.copy_(rnd(1, H, W, C, dev=dev, seed=1100, scale=1.2) + 0.1)
+        w1, b1 = rnd(Cm, C, 3, 3, dev=dev, seed=1101, scale=1.0 / math.sqrt(9 * C)), rnd(Cm, dev=dev, seed=1102, scale=0.2)
+        w2, b2 = rnd(C, Cm, 3, 3, dev=dev, seed=1103, scale=1.0 / math.sqrt(9 * Cm)), rnd(C, dev=dev, seed=1104, scale=0.2)
+        w1p, w2p = pack_conv(w1), pack_conv(w2)
+        got, pooled = ops.cab_fused(x, w1p, b1, w2p, b2)
+        c1 = ops.conv2d(x, w1p, b1, ksize=(3, 3), pad=(1, 1), act="gelu")
+        want, pooled2 = ops.conv2d(c1, w2p, b2, ksize=(3, 3), pad=(1, 1), want_pool=True)
+        assert torch.equal(got, want), float((got - want).abs().max())
+        close(pooled, pooled2, 1e-6, "pooled")
+        ref = F.conv2d(F.gelu(F.conv2d(x.permute(0, 3, 1, 2), w1, b1, padding=1)), w2, b2, padding=1).permute(0, 2, 3, 1)
+        close(got, ref, BF16_TOL, "cab fused vs fp32")
+        close(pooled, ref.mean(dim=(1, 2)), BF16_TOL, "pooled vs fp32")
+    finally:
+        ops.set_gemm_mode(prev)
