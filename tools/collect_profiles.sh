@@ -20,6 +20,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 echo "[collect] stats (multi-stream) done"
 FF_STREAMS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ss -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/bench_under_rocprof_ss.json 2> $O/stats_ss.err || exit 1
 echo "[collect] stats (single stream) done"
+# the plugin's fp32-grade mode (bf16x3), single stream: the like-for-like successor of profiles/r02_*_singlestream.csv
+FF_STREAMS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ss_x3 -- python3 bench.py --dtype bf16x3 --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/bench_under_rocprof_ss_bf16x3.json 2> $O/stats_ss_x3.err || exit 1
+python3 tools/kernel_stats_per_forward.py $O/stats_ss_x3 $O/kernels_per_forward_singlestream_bf16x3.csv || exit 1
+echo "[collect] stats (bf16x3, single stream) done"
 # per-forward tables of the library's own kernels, setup (ATen weight preparation, runtime copies) listed apart
 python3 tools/kernel_stats_per_forward.py $O/stats_ms $O/kernels_per_forward_multistream.csv || exit 1
 python3 tools/kernel_stats_per_forward.py $O/stats_ss $O/kernels_per_forward_singlestream.csv || exit 1
