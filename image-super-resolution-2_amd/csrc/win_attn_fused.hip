@@ -32,7 +32,16 @@ struct WinFusedParams {
   int B, H, W, Hp, Wp, sh, sw, use_mask, nwx, nwy;
   int head0, nheads, d, K, zero_pad, rel_rows, rel_stride, prio;
   float eps;
+#ifdef WF_TIMING
+  unsigned long long* dbg;   // tools/wf_time.cpp: [block][wave][64] wall-clock stamps (debug build only)
+#endif
 };
+#ifdef WF_TIMING
+static unsigned long long* g_wf_dbg = nullptr;
+#define WF_T(i) do { if (p.dbg && lane == 0) p.dbg[((long long)blockIdx.x * 8 + wid) * 64 + (i)] = wall_clock64(); } while (0)
+#else
+#define WF_T(i) do { } while (0)
+#endif
 
 #define WF_KS 12
 #define WF_SLOTS 25                        // 16-byte slots per weight row in LDS (24 data + 1 pad)
@@ -80,6 +89,7 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
   const int wx = bid % p.nwx; bid /= p.nwx;
   const int wy = bid % p.nwy;
   const int b = bid / p.nwy;
+  WF_T(0);
 
   // ---- weight-tile DMA: piece (wid + 8 i) of the 25 one-KiB pieces of a tile image --------------------------------------
   int off[4];
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
   // validity of the wave's 32 tokens as a bit mask (the v tile has tokens in its registers, not in its lanes)
   const unsigned vmask = (unsigned)(__ballot(tvalid) & 0xffffffffu);
   const bool kill_pad = p.zero_pad != 0;               // DAT: q/k/v of the zero-padded tokens are exactly zero
+  WF_T(1);
 
   // ---- the wave's 32 rows of x -> LayerNorm -> split-bf16 fragments ---------------------------------------------------
   bf16x8 xh[WF_KS], xl[WF_KS];
@@ -214,6 +225,7 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
     }
   }
 
+  WF_T(2);
   // lane part of the relative-position index: (qy + WH-1) * stride + qx + WW-1 - 4 hh   (window-local coordinates)
   // bias[q][k] = T[(qy - ky + WH-1) * RS + (qx - kx + WW-1)]: lane part minus a compile-time key part; written as
   // REL[rel_base + (CMAX - key part)] so every offset is a non-negative immediate of the ds_read
@@ -274,6 +286,7 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
     bf16x8 qh[2], ql[2];
     {
       ring_step();
+      WF_T(3 + 8 * hi);
       f32x16 acc;
       const int nb = it * 32 + 4 * hh;
 #pragma unroll
@@ -292,7 +305,9 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
     }
     // ---- k tile -> K[key][d-permuted] --------------------------------------------------------------------------------
     {
+      WF_T(4 + 8 * hi);
       ring_step();
+      WF_T(5 + 8 * hi);
       f32x16 acc;
       const int nb = it * 32 + 4 * hh;
 #pragma unroll
@@ -316,6 +331,7 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
     }
     // ---- v tile (operands swapped: lane = channel) -> V^T[d][key-permuted] (+ optional side output) ------------------
     {
+      WF_T(6 + 8 * hi);
       ring_step();
       f32x16 acc;
       const float bv = Bs[it * 32 + l31];
@@ -350,8 +366,10 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
       }
       ++it;
     }
+    WF_T(7 + 8 * hi);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // K, V^T and the bias table of this head are complete
+    WF_T(8 + 8 * hi);
 
     // ---- attention: 8 chunks of 32 keys, online softmax (one S^T tile live at a time: the x fragments own 96 registers) --
     f32x16 o;
@@ -428,8 +446,10 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
       m_run = m_new;
     }
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    WF_T(9 + 8 * hi);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // every wave is done with K / V^T / the bias table of this head
+    WF_T(10 + 8 * hi);
 
     // ---- O^T -> rows: transpose through the wave's own K rows (private to it until its next k tile) -----------------
     {
@@ -447,7 +467,14 @@ __global__ __launch_bounds__(512) void win_attn_fused_kernel(WinFusedParams p) {
       }
     }
   }
+  WF_T(60);
+#ifdef WF_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WF_T(61);
+#endif
 }
+
+#include "win_attn_fused_v2.inc"
 
 extern "C" int ff_win_attn_fused(const float* x, int ldx, float* out, int ldo, int o_off, const float* gamma, const float* beta,
                                  float eps, const void* w_tiles, const float* bias_padded, const float* rel_padded, int rel_rows,
@@ -475,11 +502,15 @@ extern "C" int ff_win_attn_fused(const float* x, int ldx, float* out, int ldo, i
   p.B = B; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.sh = shift_h; p.sw = shift_w; p.use_mask = use_mask;
   p.nwx = Wp / ww; p.nwy = Hp / wh; p.head0 = head0; p.nheads = nheads; p.d = d; p.K = K; p.zero_pad = zero_pad_tokens;
   p.rel_rows = rel_rows; p.rel_stride = rel_stride; p.eps = eps;
+#ifdef WF_TIMING
+  p.dbg = g_wf_dbg;
+#endif
   const long long nblk = (long long)B * p.nwx * p.nwy;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_win_attn_fused: grid too large");
   static_assert(WF_LDS <= 160 * 1024, "LDS image too large");
   static_assert(8 * 32 * WF_XS_ROW * 4 <= 8 * WF_KWAVE + 2 * WF_VPLB, "gather patch must fit in the K / V area");
-  static int unr = -1, prio = -1;
+  static int unr = -1, prio = -1, v2 = -1;
+  if (v2 < 0) { const char* e = getenv("FF_WF_V2"); v2 = (e && e[0] == '0') ? 0 : 1; }
   if (unr < 0) { const char* e = getenv("FF_WF_UNROLL"); unr = (e && e[0] == '1') ? 1 : 2; const char* q = getenv("FF_WF_PRIO"); prio = (q && q[0] == '1') ? 1 : 0; }
   p.prio = prio;
 #define WF_LAUNCH1(WWV, NT, U)                                                                                                \
@@ -494,10 +525,30 @@ extern "C" int ff_win_attn_fused(const float* x, int ldx, float* out, int ldo, i
     hipLaunchKernelGGL((win_attn_fused_kernel<WWV, NT, U>), dim3((unsigned)nblk), dim3(512), WF_LDS, (hipStream_t)stream, p); \
   } while (0)
 #define WF_LAUNCH(WWV, NT) do { if (unr == 1) WF_LAUNCH1(WWV, NT, 1); else WF_LAUNCH1(WWV, NT, 2); } while (0)
+  static_assert(W2_LDS <= 160 * 1024, "LDS image too large");
+  static_assert(8 * 32 * WF_XS_ROW * 4 <= 2 * W2_KBUF + 2 * W2_VBUF, "gather patch must fit in the K / V area");
+#define W2_LAUNCH1(WWV, ON)                                                                                                   \
+  do {                                                                                                                        \
+    static bool attr_set = false;                                                                                             \
+    if (!attr_set) {                                                                                                          \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_attn_fused_v2_kernel<WWV, ON>),                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);                                 \
+      if (e != hipSuccess) { ff_set_error("ff_win_attn_fused: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; } \
+      attr_set = true;                                                                                                        \
+    }                                                                                                                         \
+    hipLaunchKernelGGL((win_attn_fused_v2_kernel<WWV, ON>), dim3((unsigned)nblk), dim3(512), W2_LDS, (hipStream_t)stream, p); \
+  } while (0)
+#define W2_LAUNCH(WWV) do { if (d == 30) W2_LAUNCH1(WWV, true); else W2_LAUNCH1(WWV, false); } while (0)
+  if (nterms == 1 && v2) {
+    FF_CHECK_ARG((((uintptr_t)rel_padded) & 15) == 0, "ff_win_attn_fused: the bias table must be 16-byte aligned");
+    if (ww == 8) W2_LAUNCH(8); else if (ww == 16) W2_LAUNCH(16); else W2_LAUNCH(32);
+  } else
   if (nterms == 3) { if (ww == 8) WF_LAUNCH(8, 3); else if (ww == 16) WF_LAUNCH(16, 3); else WF_LAUNCH(32, 3); }
   else { if (ww == 8) WF_LAUNCH(8, 1); else if (ww == 16) WF_LAUNCH(16, 1); else WF_LAUNCH(32, 1); }
 #undef WF_LAUNCH1
 #undef WF_LAUNCH
+#undef W2_LAUNCH1
+#undef W2_LAUNCH
   FF_LAUNCH_CHECK("ff_win_attn_fused");
   return FF_OK;
 }
