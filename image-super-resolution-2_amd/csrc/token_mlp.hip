@@ -19,6 +19,7 @@
 //   * epilogue: 32x32 tiles are transposed through LDS so global stores / residual loads are 128-byte row segments.
 // Workgroup = 8 waves = 256 tokens: 65 536 tokens -> 256 workgroups = one per CU.
 #include "ff_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -335,7 +336,16 @@ struct TokenProjMlpParams {
   long long M;
   int lda, ldx, ldc, ldo, K, N, HT;
   float eps;
+#ifdef TM_TIMING
+  unsigned long long* dbg;   // tools/pm_time.cpp: [block][wave][64] wall-clock stamps (debug build only)
+#endif
 };
+#ifdef TM_TIMING
+static unsigned long long* g_tm_dbg = nullptr;
+#define TM_T(i) do { if (p.dbg && lane == 0) p.dbg[((long long)blockIdx.x * 8 + wid) * 64 + (i)] = wall_clock64(); } while (0)
+#else
+#define TM_T(i) do { } while (0)
+#endif
 
 template <int NTERMS>
 __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p) {
@@ -389,6 +399,7 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + off1[i]),
                                          (__attribute__((address_space(3))) void*)(dst + (wid + 8 * i) * 1024), 16, 0, 0);
   };
+  TM_T(0);
   dma_proj(0, 0);
   for (int i = tid; i < p.HT * 32; i += 512) B1s[i] = p.b1[i];
 
@@ -412,6 +423,7 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
     }
   }
 
+  TM_T(1);
   // ---- proj^T tiles into the output accumulators -------------------------------------------------------------------
   f32x16 oacc[6];
 #pragma unroll
@@ -447,8 +459,10 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  TM_T(2);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                          // both image areas are free again: start the MLP's first tiles
+  TM_T(3);
   dma_w1(0);
   dma_w2(0);
 
@@ -482,6 +496,7 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
       }
     }
   }
+  TM_T(4);
   // ---- LayerNorm(x1) from the accumulators -> fc1 operand (hi registers, lo rows) -------------------------------------
   {
     float s = 0.f;
@@ -523,8 +538,10 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
         *reinterpret_cast<bf16x8*>(xl_row + 32 * (2 * n + s2)) = lo;
       }
   }
+  TM_T(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  TM_T(6);
 
   // ---- the MLP over hidden tiles: identical to token_mlp_kernel (W1 columns are permuted to the operand order above) ----
   for (int ht = 0; ht < p.HT; ++ht) {
@@ -557,8 +574,10 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (ht < 3) TM_T(8 + 4 * ht);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (ht < 3) TM_T(9 + 4 * ht);
     if (ht + 1 < p.HT) dma_w1(ht + 1);
     bf16x8 gh[2], gl[2];
 #pragma unroll
@@ -595,10 +614,13 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (ht < 3) TM_T(10 + 4 * ht);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (ht < 3) TM_T(11 + 4 * ht);
     if (ht + 1 < p.HT) dma_w2(ht + 1);
   }
+  TM_T(40);
 
   // ---- epilogue: out = accumulators (x1 + fc2 part) + b2, transposed through LDS into 128-byte row segments ------------
   {
@@ -627,6 +649,311 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
       }
     }
   }
+  TM_T(41);
+#ifdef TM_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TM_T(42);
+#endif
+}
+
+// ---- plain-bf16 form of token_projmlp (nterms == 1) ----------------------------------------------------------------------------
+// Same dataflow and operand orders as the split kernel above; what changes is the schedule (phase timings of the split form,
+// tools/pm_time.cpp, 79.5 us per launch: att 8.1 | proj 6.4 | residuals 18.4 | LayerNorm 6.2 | MLP 29.3 = 12 x 2.44 | stores 6.2):
+//   * no lo planes: the six projection tiles are ONE 78-KiB LDS image fetched at kernel start (no per-tile barrier), and the
+//     MLP's W1 / W2 tiles are double buffered -- one barrier per hidden tile instead of two, each DMA a full tile ahead;
+//   * the residual slice n+1 (x, conv) is in flight while slice n is transposed and tile n+1 is projected;
+//   * gamma / beta come from LDS; GELU is x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3) -- |error| <= 4.8e-4, a sixteenth
+//     of the bf16 rounding the value receives next -- 5 full-rate + 2 transcendental operations instead of 14 + 2.
+#define PM_W1SLOT (13 * 1024)
+#define PM_W2SLOT (15 * 1024)
+#define PM_OFF_W2 (2 * PM_W1SLOT)
+#define PM_PROJB (6 * PM_W1SLOT)
+#define PM_PATCHB (32 * FF_XS_ROW * 4)
+#define PM_OFF_PATCH PM_PROJB
+#define PM_OFF_VEC (PM_OFF_PATCH + 8 * PM_PATCHB)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two GELUs at a time (the packed fp32 multiply / fma / add take both lanes of the pair in one instruction)
+__device__ __forceinline__ f32x2 ff_gelu_sig2(f32x2 x) {
+  const float A = -2.3022081f, B = -0.10294324f;       // -2 sqrt(2/pi) log2(e) * {1, 0.044715}
+  const f32x2 x2 = x * x;
+  const f32x2 pz = x2 * B + A;
+  const f32x2 z = x * pz;
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(z[0]); e[1] = __builtin_amdgcn_exp2f(z[1]);
+  const f32x2 d = e + 1.0f;
+  f32x2 r;
+  r[0] = __builtin_amdgcn_rcpf(d[0]); r[1] = __builtin_amdgcn_rcpf(d[1]);
+  return x * r;
+}
+
+__global__ __launch_bounds__(512) void token_projmlp_bf16_kernel(TokenProjMlpParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Gs = reinterpret_cast<float*>(smem + PM_OFF_VEC);
+  float* Bts = Gs + TM_KP;
+  float* B1s = Bts + TM_KP;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const long long tok0 = (long long)blockIdx.x * 256 + wid * 32;
+  float* patch = reinterpret_cast<float*>(smem + PM_OFF_PATCH + wid * PM_PATCHB);      // the wave's gather / transpose patch
+  TM_T(0);
+
+  // ---- the whole projection (6 tiles x 13 one-KiB pieces, hi plane) by LDS-DMA ----------------------------------------------
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const int pc = wid + 8 * i;
+    if (pc < 78) {
+      const int tile = pc / 13, pw = pc - 13 * tile;
+      int s = pw * 64 + lane;
+      if (s > W1PL - 1) s = W1PL - 1;
+      const int row = s / W1SLOTS;
+      int q = s - row * W1SLOTS;
+      if (q > 23) q = 23;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.wp + (long long)tile * (2 * TILE_ELEMS) + row * 192 + q * 8),
+                                       (__attribute__((address_space(3))) void*)(smem + pc * 1024), 16, 0, 0);
+    }
+  }
+  int off1[2], off2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int s = (wid + 8 * i) * 64 + lane;
+    if (s > W1PL - 1) s = W1PL - 1;
+    int row = s / W1SLOTS, q = s - row * W1SLOTS;
+    if (q > 23) q = 23;
+    off1[i] = row * 192 + q * 8;
+    s = (wid + 8 * i) * 64 + lane;
+    if (s > W2PL - 1) s = W2PL - 1;
+    row = s / W2SLOTS; q = s - row * W2SLOTS;
+    if (q > 3) q = 3;
+    off2[i] = 2 * TILE_ELEMS + row * 32 + q * 8;
+  }
+  auto dma_mlp = [&](int ht, int slot) {
+    const __bf16* rec = p.w + (long long)ht * (4 * TILE_ELEMS);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (wid + 8 * i < 13)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + off1[i]),
+                                         (__attribute__((address_space(3))) void*)(smem + slot * PM_W1SLOT + (wid + 8 * i) * 1024), 16, 0, 0);
+      if (wid + 8 * i < 15)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + off2[i]),
+                                         (__attribute__((address_space(3))) void*)(smem + PM_OFF_W2 + slot * PM_W2SLOT + (wid + 8 * i) * 1024), 16, 0, 0);
+    }
+  };
+  for (int i = tid; i < p.HT * 32; i += 512) B1s[i] = p.b1[i];
+  if (tid < TM_KP) { Gs[tid] = tid < p.K ? p.gamma[tid] : 0.f; Bts[tid] = tid < p.K ? p.beta[tid] : 0.f; }
+
+  // ---- att rows -> bf16 fragments -------------------------------------------------------------------------------------------
+  bf16x8 xh[TM_KS];
+  {
+    float v[TM_KS][8];
+    ff_wave_rows_to_frags<3>(p.att, p.lda, tok0, p.M, p.K, patch, lane, v);
+#pragma unroll
+    for (int st = 0; st < TM_KS; ++st)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xh[st][j] = (__bf16)v[st][j];
+  }
+  TM_T(1);
+
+  // ---- residual slices: coalesced float4 loads (lane = token row lane>>3 (+8i), channel quad), one slice ahead ----------------
+  const int tq = lane >> 3, q4 = 4 * (lane & 7);
+  f32x4 rx[4], rc[4];
+  // 32-bit element offsets of the lane's four token rows (launcher: M * ld < 2^31); rows past M read row 0 and channels past N
+  // read channel 0 instead -- finite values that are never stored and that the zero-padded gamma / beta keep out of fc1
+  int xo[4], co[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long tk = tok0 + tq + 8 * i;
+    const int t = tk < p.M ? (int)tk : 0;
+    xo[i] = t * p.ldx + q4;
+    co[i] = t * p.ldc + q4;
+  }
+  auto load_res = [&](int n) {
+    const int cn = (n * 32 + q4 < p.N) ? n * 32 : -q4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rx[i] = *reinterpret_cast<const f32x4*>(p.x + (xo[i] + cn));
+      if (p.c2) rc[i] = *reinterpret_cast<const f32x4*>(p.c2 + (co[i] + cn));
+    }
+  };
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // the projection image, the vectors and the fragments are in place
+
+  f32x16 oacc[6];
+#pragma unroll
+  for (int n = 0; n < 6; ++n) {
+    const float* bpn = p.bp + n * 32 + 4 * hh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[n][r] = bpn[(r & 3) + 8 * (r >> 2)];
+    const unsigned char* ap = smem + n * PM_W1SLOT + l31 * W1ROWB + 16 * hh;
+    bf16x8 fa[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) fa[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u);
+#pragma unroll
+    for (int st = 0; st < TM_KS; ++st) {
+      const bf16x8 ah = fa[st & 1];
+      if (st + 2 < TM_KS) fa[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2));
+      __builtin_amdgcn_sched_barrier(0);
+      oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], oacc[n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  TM_T(2);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // every wave is past the projection image: the MLP's first two tiles may land on it
+  TM_T(3);
+  dma_mlp(0, 0);
+  if (p.HT > 1) dma_mlp(1, 1);
+#pragma unroll
+  for (int n = 0; n < 6; ++n) {
+    // x1 = proj + shortcut + conv * scale, slice n: through the wave's patch into accumulator order
+    {
+      load_res(n);
+      const int c4 = n * 32 + q4;
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+      if (p.c2 && c4 < p.N) sc = *reinterpret_cast<const f32x4*>(p.rs2 + c4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 r0 = rx[i];
+        if (p.c2) r0 += rc[i] * sc;
+        *reinterpret_cast<f32x4*>(patch + (tq + 8 * i) * 36 + q4) = r0;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(patch + l31 * 36 + 8 * g + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) oacc[n][4 * g + e] += u[e];
+      }
+    }
+  }
+  TM_T(4);
+
+  // ---- LayerNorm(x1) from the accumulators -> fc1 operand --------------------------------------------------------------------
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += (n * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < p.K) ? oacc[n][r] : 0.f;
+    s += __shfl_xor(s, 32);
+    const float mean = s / (float)p.K;
+    float qv = 0.f;
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = (n * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < p.K) ? oacc[n][r] - mean : 0.f;
+        qv += d * d;
+      }
+    qv += __shfl_xor(qv, 32);
+    const float rstd = 1.0f / sqrtf(qv / (float)p.K + p.eps);
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          const int c0 = n * 32 + 8 * (2 * s2 + g2) + 4 * hh;           // channels of registers 8 s2 + 4 g2 .. + 3 (< 192: the vectors are zero padded)
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(Gs + c0);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bts + c0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            xh[2 * n + s2][4 * g2 + e] = (__bf16)((oacc[n][8 * s2 + 4 * g2 + e] - mean) * rstd * g4[e] + b4[e]);
+        }
+        // the fragment is pinned here: left to itself the scheduler issues all 48 vector reads first and sinks the arithmetic
+        // below them (192 live registers, 52 of them spilled)
+        asm volatile("" : "+v"(xh[2 * n + s2]) :: "memory");
+      }
+  }
+  TM_T(5);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // tiles 0 and 1 of the MLP have landed
+  TM_T(6);
+
+  // ---- the MLP over hidden tiles ---------------------------------------------------------------------------------------------
+  for (int ht = 0; ht < p.HT; ++ht) {
+    const int slot = ht & 1;
+    f32x16 hacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hacc[r] = B1s[ht * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+    {
+      const unsigned char* ap = smem + slot * PM_W1SLOT + l31 * W1ROWB + 16 * hh;
+      bf16x8 fa[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) fa[u] = *reinterpret_cast<const bf16x8*>(ap + 32 * u);
+#pragma unroll
+      for (int st = 0; st < TM_KS; ++st) {
+        const bf16x8 ah = fa[st & 1];
+        if (st + 2 < TM_KS) fa[st & 1] = *reinterpret_cast<const bf16x8*>(ap + 32 * (st + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[st], hacc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (ht < 3) TM_T(8 + 4 * ht);
+    bf16x8 gh[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const f32x2 g = ff_gelu_sig2((f32x2){hacc[8 * s + j], hacc[8 * s + j + 1]});
+        gh[s][j] = (__bf16)g[0];
+        gh[s][j + 1] = (__bf16)g[1];
+      }
+    if (ht < 3) TM_T(9 + 4 * ht);
+    {
+      const unsigned char* ap = smem + PM_OFF_W2 + slot * PM_W2SLOT + l31 * W2ROWB + 16 * hh;
+      bf16x8 fa[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) fa[u] = *reinterpret_cast<const bf16x8*>(ap + (u >> 1) * 32 * W2ROWB + 32 * (u & 1));
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int n = u >> 1, s2 = u & 1;
+        const bf16x8 ah = fa[u & 1];
+        if (u + 2 < 12) fa[u & 1] = *reinterpret_cast<const bf16x8*>(ap + ((u + 2) >> 1) * 32 * W2ROWB + 32 * ((u + 2) & 1));
+        __builtin_amdgcn_sched_barrier(0);
+        oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh[s2], oacc[n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (ht < 3) TM_T(10 + 4 * ht);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // every wave is done with this slot; tile ht+1 has landed everywhere
+    if (ht < 3) TM_T(11 + 4 * ht);
+    if (ht + 2 < p.HT) dma_mlp(ht + 2, slot);
+  }
+  TM_T(40);
+
+  // ---- epilogue: out = accumulators (x1 + fc2 part) + b2, transposed through the wave's patch into 128-byte row segments -----
+  {
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const int c4 = n * 32 + q4;
+      const bool cok = c4 < p.N;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.b2 + (cok ? c4 : 0));
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = oacc[n][4 * g + e];
+        *reinterpret_cast<f32x4*>(patch + l31 * 36 + 8 * g + 4 * hh) = v4;
+      }
+      f32x4 ov[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ov[i] = *reinterpret_cast<const f32x4*>(patch + (tq + 8 * i) * 36 + q4) + b4;
+      if (cok) {
+        float* op = p.out + (tok0 + tq) * p.ldo + c4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (tok0 + tq + 8 * i < p.M) *reinterpret_cast<f32x4*>(op + (long long)(8 * i) * p.ldo) = ov[i];
+      }
+    }
+  }
+  TM_T(41);
+#ifdef TM_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TM_T(42);
+#endif
 }
 
 extern "C" int ff_token_projmlp(const float* att, int lda, const float* x, int ldx, const float* c2, int ldc, const float* c2_scale,
@@ -646,10 +973,14 @@ extern "C" int ff_token_projmlp(const float* att, int lda, const float* x, int l
   p.att = att; p.x = x; p.c2 = c2; p.rs2 = c2_scale; p.out = out; p.gamma = gamma; p.beta = beta;
   p.wp = (const __bf16*)proj_tiles; p.bp = proj_bias_padded; p.w = (const __bf16*)mlp_tiles; p.b1 = b1_padded; p.b2 = b2;
   p.M = M; p.lda = lda; p.ldx = ldx; p.ldc = ldc; p.ldo = ldo; p.K = K; p.N = K; p.HT = hidden_tiles; p.eps = eps;
+#ifdef TM_TIMING
+  p.dbg = g_tm_dbg;
+#endif
   const size_t lds = (size_t)(2 * W1PL + 2 * W2PL) * 16 + (size_t)8 * 32 * XLROWB + (size_t)hidden_tiles * 32 * 4;
   FF_CHECK_ARG(lds <= 160 * 1024, "ff_token_projmlp: hidden too large for the LDS image");
   const long long nblk = (M + 255) / 256;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_token_projmlp: grid too large");
+  FF_CHECK_ARG(M * (long long)(ldx > ldc ? ldx : ldc) < (1LL << 31), "ff_token_projmlp: too many tokens for 32-bit row offsets");
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_projmlp_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -657,7 +988,19 @@ extern "C" int ff_token_projmlp(const float* att, int lda, const float* x, int l
     if (e != hipSuccess) { ff_set_error("ff_token_projmlp: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
     attr_set = true;
   }
-  if (nterms == 3) hipLaunchKernelGGL(token_projmlp_kernel<3>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  static int v2 = -1;
+  if (v2 < 0) { const char* e = getenv("FF_PM_V2"); v2 = (e && e[0] == '0') ? 0 : 1; }
+  if (nterms == 1 && v2) {
+    const size_t lds2 = (size_t)PM_OFF_VEC + (size_t)(2 * TM_KP + hidden_tiles * 32) * 4;
+    FF_CHECK_ARG(lds2 <= 160 * 1024, "ff_token_projmlp: hidden too large for the LDS image");
+    static bool attr2 = false;
+    if (!attr2) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_projmlp_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { ff_set_error("ff_token_projmlp: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return FF_ERR_LAUNCH; }
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(token_projmlp_bf16_kernel, dim3((unsigned)nblk), dim3(512), lds2, (hipStream_t)stream, p);
+  } else if (nterms == 3) hipLaunchKernelGGL(token_projmlp_kernel<3>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(token_projmlp_kernel<1>, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
   FF_LAUNCH_CHECK("ff_token_projmlp");
   return FF_OK;

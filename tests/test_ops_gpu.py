@@ -808,8 +808,9 @@ def test_win_attn_fused_dat_branches(dev, mode, H, W, shifted):
         ops.set_gemm_mode(prev)
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("M,with_conv", [(65536, True), (1000, True), (77, False), (4096, False)])
-def test_token_projmlp_fused(dev, M, with_conv):
+def test_token_projmlp_fused(dev, mode, M, with_conv):
     """proj + shortcut + conv_x * scale + norm2 + MLP in one launch (hat_arch.py:303-307) against the PyTorch fp32 chain."""
     from isr2_amd import ops
     from isr2_amd.prep import pack_token_projmlp
@@ -828,8 +829,13 @@ def test_token_projmlp_fused(dev, M, with_conv):
     x1 = x + F.linear(att, wp, bp) + (c2 * scale if with_conv else 0.0)
     ref = x1 + F.linear(F.gelu(F.linear(F.layer_norm(x1, (C,), g, b, 1e-5), w1, b1)), w2, b2)
     pk = pack_token_projmlp(wp, bp, w1, b1, w2, b2)
-    out = ops.token_projmlp(att, x, pk, g, b, c2=c2 if with_conv else None, c2_scale=scale if with_conv else None)
-    close(out, ref, 6e-5, "token_projmlp")
+    prev = ops.gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        out = ops.token_projmlp(att, x, pk, g, b, c2=c2 if with_conv else None, c2_scale=scale if with_conv else None)
+    finally:
+        ops.set_gemm_mode(prev)
+    close(out, ref, GEMM_TOL[mode], "token_projmlp")
 
 
 @pytest.mark.parametrize("H,W", [(256, 256), (37, 45)])
