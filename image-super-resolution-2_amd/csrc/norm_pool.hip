@@ -174,6 +174,31 @@ extern "C" int ff_pool_mean(const float* in, int ld, int B, long long P, int C, 
   return FF_OK;
 }
 
+// first stage alone (one image): ff_pool_partial_rows(P) rows of C partial sums, for ff_pool_vec_mlp / ff_pool_finish
+static int pool_chunks(long long P, int* ppc_out) {
+  int nch = (int)((P + 255) / 256);
+  if (nch > 1024) nch = 1024;
+  const int ppc = (int)((P + nch - 1) / nch);
+  if (ppc_out) *ppc_out = ppc;
+  return (int)((P + ppc - 1) / ppc);
+}
+extern "C" int ff_pool_partial_rows(long long P) { return P > 0 ? pool_chunks(P, nullptr) : 0; }
+extern "C" int ff_pool_partials(const float* in, int ld, long long P, int C, float* part, long long part_floats, void* stream) {
+  FF_CHECK_ARG(in && part && P > 0 && C > 0 && ld >= C, "ff_pool_partials: bad args");
+  int ppc;
+  const int nch = pool_chunks(P, &ppc);
+  FF_CHECK_ARG(part_floats >= (long long)nch * C, "ff_pool_partials: need %lld floats", (long long)nch * C);
+  const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && (C / 4 <= 256) && (((uintptr_t)in & 15) == 0) && (((uintptr_t)part & 15) == 0);
+  if (v4) {
+    const int cv = C / 4, rpi = 256 / cv;
+    hipLaunchKernelGGL(pool_partial_v4_kernel, dim3(nch, 1), dim3(256), (size_t)rpi * cv * 16, (hipStream_t)stream, in, ld, P, C, ppc, part);
+  } else {
+    hipLaunchKernelGGL(pool_partial_kernel, dim3(nch, 1), dim3(256), 0, (hipStream_t)stream, in, ld, P, C, ppc, part);
+  }
+  FF_LAUNCH_CHECK("ff_pool_partials");
+  return FF_OK;
+}
+
 // second stage alone: out[c] = inv_count * sum_r part[r][c] over `rows` rows of pitch ld (per-workgroup partials written by a
 // producer kernel's epilogue, e.g. ff_conv3x3_halo pool_partials)
 extern "C" int ff_pool_finish(const float* part, int rows, int ld, int C, float inv_count, float* out, void* stream) {
@@ -245,6 +270,71 @@ extern "C" int ff_vec_mlp(const float* in, int B, int Cin, const float* W1, cons
   hipLaunchKernelGGL(vec_mlp_kernel, dim3(gx, B), dim3(256), (size_t)(Cin + Ch) * 4, (hipStream_t)stream, in, Cin, W1, b1, Ch,
                      act1, W2, b2, Cout, act2, post, out);
   FF_LAUNCH_CHECK("ff_vec_mlp");
+  return FF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pool finish + two-layer vector MLP in ONE single-workgroup launch (channel attention behind a conv's pool partials,
+// hat_arch.py:50-54):  v[c] = inv_count * sum_r part[r][c];  out = act2(W2 . act1(W1 . v + b1) + b2) * post.
+// Replaces ff_pool_finish + ff_vec_mlp (two dependent ~7 us launches on a block's critical path).  1024 threads: 16 row groups
+// x 64 channel lanes for the reduction (4 independent accumulators per thread), then a wave per hidden unit, a thread per output.
+__global__ __launch_bounds__(1024) void pool_vec_mlp_kernel(const float* __restrict__ part, int rows, int ld, float inv, int Cin,
+                                                            const float* __restrict__ W1, const float* __restrict__ b1, int Ch, int act1,
+                                                            const float* __restrict__ W2, const float* __restrict__ b2, int Cout, int act2,
+                                                            float post, float* __restrict__ out, float* __restrict__ pooled) {
+  extern __shared__ float sm[];
+  float* red = sm;                       // [16][64]
+  float* xin = sm + 16 * 64;             // [Cin]
+  float* hid = xin + Cin;                // [Ch]
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < Cin; c0 += 64) {
+    const int c = c0 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < Cin) {
+      const float* pp = part + c;
+      int r = rg;
+      for (; r + 48 < rows; r += 64) {
+        s0 += pp[(long long)r * ld];
+        s1 += pp[(long long)(r + 16) * ld];
+        s2 += pp[(long long)(r + 32) * ld];
+        s3 += pp[(long long)(r + 48) * ld];
+      }
+      for (; r < rows; r += 16) s0 += pp[(long long)r * ld];
+    }
+    red[rg * 64 + lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && c < Cin) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k * 64 + lane];
+      t *= inv;
+      xin[c] = t;
+      if (pooled) pooled[c] = t;
+    }
+    __syncthreads();
+  }
+  for (int j = rg; j < Ch; j += 16) {
+    float s = 0.f;
+    for (int i = lane; i < Cin; i += 64) s += W1[(long long)j * Cin + i] * xin[i];
+    s = wave_sum(s);
+    if (lane == 0) hid[j] = ff_act(s + (b1 ? b1[j] : 0.f), act1);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < Cout; o += 1024) {
+    float s = b2 ? b2[o] : 0.f;
+    for (int i = 0; i < Ch; ++i) s += W2[(long long)o * Ch + i] * hid[i];
+    out[o] = ff_act(s, act2) * post;
+  }
+}
+
+extern "C" int ff_pool_vec_mlp(const float* part, int rows, int ld, float inv_count, int Cin, const float* W1, const float* b1, int Ch,
+                               int act1, const float* W2, const float* b2, int Cout, int act2, float post, float* out,
+                               float* pooled_out, void* stream) {
+  FF_CHECK_ARG(part && W1 && W2 && out, "ff_pool_vec_mlp: null pointer");
+  FF_CHECK_ARG(rows > 0 && Cin > 0 && ld >= Cin && Ch > 0 && Ch <= 64 && Cout > 0 && Cin <= 4096, "ff_pool_vec_mlp: bad dims (hidden width <= 64)");
+  hipLaunchKernelGGL(pool_vec_mlp_kernel, dim3(1), dim3(1024), (size_t)(16 * 64 + Cin + Ch) * 4, (hipStream_t)stream, part, rows, ld,
+                     inv_count, Cin, W1, b1, Ch, act1, W2, b2, Cout, act2, post, out, pooled_out);
+  FF_LAUNCH_CHECK("ff_pool_vec_mlp");
   return FF_OK;
 }
 

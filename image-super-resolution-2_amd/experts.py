@@ -195,10 +195,10 @@ class HatHIP:
                             kwin=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, heads=self.heads, d=d, scale=d ** -0.5,
                             rel_table=blk["rel"] if _REL_BIAS else None)
         if _CAB_FUSED and ops.gemm_mode() == "bf16" and blk["cab0"][0].shape[0] <= 64 and C <= 192 and x.shape[0] == 1:
-            c2, c2mean = ops.cab_fused(xn, blk["cab0"][0], blk["cab0"][1], blk["cab2"][0], blk["cab2"][1])    # conv -> GELU -> conv + pool, one launch
+            c2, c2mean = ops.cab_fused(xn, blk["cab0"][0], blk["cab0"][1], blk["cab2"][0], blk["cab2"][1], partials=True)   # conv -> GELU -> conv + pool, one launch
         else:
             c1 = ops.conv2d(xn, *blk["cab0"], ksize=(3, 3), pad=(1, 1), act="gelu")
-            c2, c2mean = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1), want_pool=True)   # pool from the conv epilogue
+            c2, c2mean = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1), want_pool="partials")   # pool partials from the conv epilogue
         gate = ops.vec_mlp(c2mean, *blk["ca1"], "relu", *blk["ca2"], "sigmoid", post=self.conv_scale)
         if _fast() and _PROJ_MLP:                                  # proj + both residuals + norm2 + MLP: x1 never reaches memory
             return ops.token_projmlp(att, x, _pm(blk), blk["n2"][0], blk["n2"][1], c2=c2, c2_scale=gate.reshape(-1))
@@ -404,7 +404,7 @@ class DatHIP:
                 wbd = ops.chan_attn_weights(qkv, 0, C, blk["temp"])
             att = ops.linear(v, wbd, dynamic_w=True)
             ch_in, sp_in = att, conv_x
-        cm = ops.vec_mlp(ops.pool_mean(ch_in), *blk["ci1"], "gelu", *blk["ci4"], "sigmoid")              # [1,C]
+        cm = ops.vec_mlp(ops.pool_partials(ch_in), *blk["ci1"], "gelu", *blk["ci4"], "sigmoid")          # [1,C]; pool finish inside the MLP launch
         if _fast() and _GATED_PROJ:
             # spatial gate (from sp_in, applied to ch_in) + channel gate (applied to sp_in) + projection + residual in one launch
             if "gp_pk" not in blk:

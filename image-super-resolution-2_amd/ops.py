@@ -158,6 +158,9 @@ _PERSIST_GRAPH: Dict[tuple, Dict[tuple, T]] = {}
 _PERSIST_EAGER: Dict[tuple, T] = {}
 
 
+_POOL_MLP = _os.environ.get("FF_POOL_MLP", "1") != "0"     # pool finish + channel-attention MLP in one launch
+
+
 def set_capture_key(key) -> None:
     global _CAPTURE_KEY
     _CAPTURE_KEY = key
@@ -322,12 +325,27 @@ def _nhwc(t: T, name: str):
     return p, ld, t.shape[0], t.shape[1], t.shape[2], c
 
 
+class PoolPartials:
+    """Per-workgroup pool partial sums written by a conv epilogue: mean[c] = inv_count * sum_r part[r][c].  vec_mlp() consumes
+    them directly (ff_pool_vec_mlp: finish + channel-attention MLP in one launch); .mean() finishes them alone."""
+
+    def __init__(self, part: T, C: int, inv_count: float):
+        self.part, self.C, self.inv_count = part, C, inv_count
+
+    def mean(self) -> T:
+        pooled = torch.empty((1, self.C), device=self.part.device, dtype=torch.float32)
+        _lib.check(_L().ff_pool_finish(self.part.data_ptr(), self.part.shape[0], self.part.shape[1], self.C, self.inv_count,
+                                       pooled.data_ptr(), _stream()))
+        return pooled
+
+
 def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1), pad=(0, 0), act=None,
            res: Optional[T] = None, mul: Optional[T] = None, alpha: float = 1.0, shuffle: int = 0,
            out: Optional[T] = None, tile_hint: int = 0, dynamic_w: bool = False, want_pool: bool = False):
     """x [B,H,W,Cin] (rows view), w packed [Cout, KH*KW*Cin] -> [B,Ho,Wo,Cout] (or pixel-shuffled).
     want_pool (B == 1): also return the global average pool [1, Cout] of the output -> (out, pooled); the LDS-resident 3x3
-    kernel produces it from its epilogue, any other path falls back to ff_pool_mean on the output."""
+    kernel produces it from its epilogue, any other path falls back to ff_pool_mean on the output.  want_pool="partials":
+    the second value is a PoolPartials when the epilogue produced partial sums (else the finished pool)."""
     xp, ldi, B, H, W, Cin = _nhwc(x, "conv2d.x")
     KH, KW = ksize
     Cout = w.shape[0]
@@ -378,10 +396,9 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
         _lib.check(_L().ff_conv3x3_halo(xp, ldi, img[0].data_ptr(), img[1], _ptr(bias), _ptr(mul), rp, ldr, op, ldo, B, H, W,
                                         Cin, Cout, ACT[act], float(alpha), shuffle, _ptr(part), _nterms(), _stream()))
         if part is not None:
-            pooled = torch.empty((1, Cout), device=x.device, dtype=torch.float32)
-            _lib.check(_L().ff_pool_finish(part.data_ptr(), part.shape[0], img[1], Cout, 1.0 / float(H * W), pooled.data_ptr(), _stream()))
+            pp = PoolPartials(part, Cout, 1.0 / float(H * W))
             _note(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, 4.0 * (_numel(x, w, out, res)))
-            return out, pooled
+            return out, (pp if want_pool == "partials" else pp.mean())
     else:
         aligned = (ldi % 4 == 0) and (xp % 16 == 0)
         hi, lo, Kp, Cp, _ = _split_weight(w, dynamic_w, Cin if aligned else 0)
@@ -395,7 +412,7 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
     return out
 
 
-def cab_fused(x: T, w1: T, b1: T, w2: T, b2: T):
+def cab_fused(x: T, w1: T, b1: T, w2: T, b2: T, partials: bool = False):
     """HAT's CAB in one launch (plain bf16 only): conv3x3(x, w1) + b1 -> GELU -> conv3x3(., w2) + b2 and the global average pool of the
     result.  x [1,H,W,Cin] rows view, w1 / w2 packed [Cmid, 9*Cin] / [Cout, 9*Cmid] -> (out [1,H,W,Cout], pooled [1,Cout])."""
     if _GEMM_MODE != "bf16":
@@ -411,12 +428,11 @@ def cab_fused(x: T, w1: T, b1: T, w2: T, b2: T):
     op, ldo, *_ = _nhwc(out, "cab_fused.out")
     prow = int(_L().ff_cab_fused_pool_rows(H, W))
     part = torch.empty((prow, 192), device=x.device, dtype=torch.float32)
-    pooled = torch.empty((1, Cout), device=x.device, dtype=torch.float32)
     _lib.check(_L().ff_cab_fused(xp, ldi, i1.data_ptr(), b1.data_ptr(), i2.data_ptr(), b2.data_ptr(), op, ldo, H, W, Cin, Cmid, Cout,
                                  part.data_ptr(), _stream()))
-    _lib.check(_L().ff_pool_finish(part.data_ptr(), prow, 192, Cout, 1.0 / float(H * W), pooled.data_ptr(), _stream()))
+    pp = PoolPartials(part, Cout, 1.0 / float(H * W))
     _note(2.0 * H * W * 9 * (Cmid * Cin + Cout * Cmid), 4.0 * H * W * (Cin + Cout))
-    return out, pooled
+    return out, (pp if partials else pp.mean())
 
 
 def linear(x: T, w: T, bias: Optional[T] = None, *, act=None, res: Optional[T] = None, mul: Optional[T] = None,
@@ -667,6 +683,18 @@ def layernorm(x: T, gamma: T, beta: T, eps: float = 1e-5, out: Optional[T] = Non
     return out
 
 
+def pool_partials(x: T):
+    """First stage of the global average pool of one image [1,H,W,C] -> PoolPartials (vec_mlp finishes them in its own launch)."""
+    xp, ld, B, H, W, C = _nhwc(x, "pool_partials.x")
+    if B != 1 or not _POOL_MLP:
+        return pool_mean(x)
+    P = H * W
+    rows = int(_L().ff_pool_partial_rows(P))
+    part = torch.empty((rows, C), device=x.device, dtype=torch.float32)
+    _lib.check(_L().ff_pool_partials(xp, ld, P, C, part.data_ptr(), part.numel(), _stream()))
+    return PoolPartials(part, C, 1.0 / float(P))
+
+
 def pool_mean(x: T) -> T:
     """[B,H,W,C] rows view -> [B,C]."""
     xp, ld, B, H, W, C = _nhwc(x, "pool_mean.x")
@@ -679,8 +707,20 @@ def pool_mean(x: T) -> T:
     return out
 
 
-def vec_mlp(v: T, W1: T, b1: Optional[T], act1, W2: Optional[T] = None, b2: Optional[T] = None, act2=None,
+def vec_mlp(v, W1: T, b1: Optional[T], act1, W2: Optional[T] = None, b2: Optional[T] = None, act2=None,
             post: float = 1.0) -> T:
+    """act2(W2 . act1(W1 . v + b1) + b2) * post per row of v [B, Cin] (W2 None: one layer).  v may be a PoolPartials: the pool is
+    then finished inside the same launch (two-layer form with a hidden width <= 64), otherwise finished first."""
+    if isinstance(v, PoolPartials):
+        if W2 is not None and W1.shape[0] <= 64 and _POOL_MLP:
+            if W1.shape[1] != v.C or W2.shape[1] != W1.shape[0]:
+                raise _lib.FFError("vec_mlp: weight shape mismatch")
+            out = torch.empty((1, W2.shape[0]), device=v.part.device, dtype=torch.float32)
+            _lib.check(_L().ff_pool_vec_mlp(v.part.data_ptr(), v.part.shape[0], v.part.shape[1], v.inv_count, v.C, W1.data_ptr(), _ptr(b1),
+                                            W1.shape[0], ACT[act1], W2.data_ptr(), _ptr(b2), W2.shape[0], ACT[act2], float(post),
+                                            out.data_ptr(), None, _stream()))
+            return out
+        v = v.mean()
     B, Cin = v.shape
     Ch = W1.shape[0]
     Cout = W2.shape[0] if W2 is not None else Ch

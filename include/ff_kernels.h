@@ -230,6 +230,18 @@ long long ff_pool_mean_workspace(int B, long long P, int C);
 int ff_vec_mlp(const float* in, int B, int Cin, const float* W1, const float* b1, int Ch, int act1, const float* W2,
                const float* b2, int Cout, int act2, float post, float* out, void* stream);
 
+/* First stage of ff_pool_mean alone (one image of P pixels): part[ff_pool_partial_rows(P)][C] partial sums, to be finished by
+ * ff_pool_vec_mlp or ff_pool_finish (inv_count = 1 / P, ld = C). */
+int ff_pool_partial_rows(long long P);
+int ff_pool_partials(const float* in, int ld, long long P, int C, float* part, long long part_floats, void* stream);
+
+/* ff_pool_finish + the two-layer ff_vec_mlp in one single-workgroup launch (one image, hidden width <= 64):
+ *   v[c] = inv_count * sum_r part[r][c] (r < rows, pitch ld);  out = act2(W2 . act1(W1 . v + b1) + b2) * post;
+ * pooled_out (may be NULL) receives v.  The channel attention behind a conv's pool partials, hat_arch.py:50-54. */
+int ff_pool_vec_mlp(const float* part, int rows, int ld, float inv_count, int Cin, const float* W1, const float* b1, int Ch,
+                    int act1, const float* W2, const float* b2, int Cout, int act2, float post, float* out, float* pooled_out,
+                    void* stream);
+
 /* Depth-wise conv, NHWC, zero padding, weights tap-major [KH*KW][C]:
  *   out = act((sum w*x + bias) * post_scale + post_shift) * mul_in[pixel][c]     (mul_in may be NULL)
  * dat_arch.py:109,403-407; nafnet_arch.py:78-81; large_kernel_attention.py:59-73; edge_enhancement.py:62. */

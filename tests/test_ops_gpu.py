@@ -1090,3 +1090,23 @@ def test_cab_fused_equals_the_two_launch_path(dev, H, W):
         close(pooled, ref.mean(dim=(1, 2)), BF16_TOL, "pooled vs fp32")
     finally:
         ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("rows,C,Ch", [(256, 180, 6), (1024, 180, 22), (7, 64, 4), (300, 200, 64)])
+def test_pool_vec_mlp_fused(dev, rows, C, Ch):
+    """Pool finish + channel-attention MLP in one launch (hat_arch.py:50-54; dat_arch.py:412-416) against the two launches it
+    replaces and against torch; also the first pool stage alone (ff_pool_partials)."""
+    from isr2_amd import ops
+    part = rnd(rows, C, dev=dev, seed=900, scale=3.0)
+    W1, b1 = rnd(Ch, C, dev=dev, seed=901, scale=0.2), rnd(Ch, dev=dev, seed=902, scale=0.1)
+    W2, b2 = rnd(C, Ch, dev=dev, seed=903, scale=0.5), rnd(C, dev=dev, seed=904, scale=0.1)
+    pp = ops.PoolPartials(part, C, 1.0 / 4096.0)
+    fused = ops.vec_mlp(pp, W1, b1, "relu", W2, b2, "sigmoid", post=0.01)
+    two = ops.vec_mlp(pp.mean(), W1, b1, "relu", W2, b2, "sigmoid", post=0.01)
+    v = part.double().sum(0, keepdim=True) / 4096.0
+    ref = torch.sigmoid(F.linear(torch.relu(F.linear(v, W1.double(), b1.double())), W2.double(), b2.double())) * 0.01
+    close(fused, ref.float(), 2e-6, "fused vs torch")
+    close(fused, two, 2e-6, "fused vs two launches")
+    x = rnd(1, 37, 29, C, dev=dev, seed=905)
+    p2 = ops.pool_partials(x)
+    close(p2.mean(), x.mean((1, 2)), 2e-6, "pool partials")
