@@ -51,6 +51,7 @@ def _tl(blk: dict, key: str) -> dict:
     return pk
 
 
+_SGFN_TAIL = os.environ.get("FF_SGFN_TAIL", "1") != "0"      # plain bf16: DAT's SpatialGate + fc2 + residual in one launch
 _CAB_FUSED = os.environ.get("FF_CAB_FUSED", "0") == "1"        # opt-in: HAT's conv branch in one launch (csrc/cab_fused.hip); bit-identical to the two launches, measured no faster
 
 
@@ -428,6 +429,9 @@ class DatHIP:
             # fc1 + GELU also emits the SpatialGate LayerNorm statistics of its upper half; the depth-wise conv normalises on load
             c2 = blk["fc1"][0].shape[0] // 2
             y, stats = ops.token_linear(x, _tl(blk, "fc1"), gamma=blk["n2"][0], beta=blk["n2"][1], act="gelu", stats_range=(c2, 2 * c2))
+            if _SGFN_TAIL and ops.gemm_mode() == "bf16" and blk["fc2"][0].shape[0] <= 192 and c2 % 4 == 0 and c2 <= 512:
+                # SpatialGate + fc2 + residual in one launch: the gate product never reaches memory (csrc/sgfn_tail.hip)
+                return ops.sgfn_tail(y, c2, blk["sgc"][0], blk["sgc"][1], stats, blk["sgn"][0], blk["sgn"][1], blk["fc2"][0], blk["fc2"][1], res=x)
             z = ops.dwconv3x3_ln(y[..., c2:], blk["sgc"][0], blk["sgc"][1], stats, blk["sgn"][0], blk["sgn"][1], mul_in=y[..., :c2])
             return ops.linear(z, *blk["fc2"], res=x)
         if _fast():

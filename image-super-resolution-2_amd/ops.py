@@ -807,6 +807,31 @@ def dwconv3x3_ln(x: T, w_tap: T, bias: Optional[T], stats: T, gamma: T, beta: T,
     return out
 
 
+def sgfn_tail(y: T, c2: int, w_tap: T, dw_bias: Optional[T], stats: T, gamma: T, beta: T, w2: T, b2: Optional[T], res: Optional[T] = None) -> T:
+    """res + fc2(y[..., :c2] * (dw3x3(LayerNorm(y[..., c2:2 c2])) + dw_bias)) + b2 in one launch (plain bf16; csrc/sgfn_tail.hip).
+    y [B,H,W,>= 2 c2] rows view (fc1's output), stats [B*H*W, 2] = (mean, rstd) of y[..., c2:], w_tap [9, c2], w2 [N, c2]."""
+    if _GEMM_MODE != "bf16":
+        raise _lib.FFError("sgfn_tail exists for the plain-bf16 contraction mode only")
+    yp, ldh, B, H, W, Cy = _nhwc(y, "sgfn_tail.y")
+    N = w2.shape[0]
+    if Cy < 2 * c2 or tuple(w_tap.shape) != (9, c2) or tuple(stats.shape) != (B * H * W, 2) or gamma.numel() != c2 or beta.numel() != c2 \
+            or w2.shape[1] != c2:
+        raise _lib.FFError("sgfn_tail: shape mismatch")
+    from . import prep as _prep
+    tiles = PREPARED.get(w2, "sgfn", lambda: _prep.pack_sgfn_fc2(w2))
+    out = empty_rows((B, H, W, N), y.device)
+    op, ldo, *_ = _nhwc(out, "sgfn_tail.out")
+    rp, ldr = None, 0
+    if res is not None:
+        if tuple(res.shape) != (B, H, W, N):
+            raise _lib.FFError("sgfn_tail: res shape mismatch")
+        rp, ldr, *_ = _nhwc(res, "sgfn_tail.res")
+    _lib.check(_L().ff_sgfn_tail(yp, ldh, c2, stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w_tap.data_ptr(), _ptr(dw_bias),
+                                 tiles.data_ptr(), tiles.shape[0], _ptr(b2), rp, ldr, op, ldo, B, H, W, N, _stream()))
+    _note(2.0 * B * H * W * c2 * (9 + N), 4.0 * B * H * W * (2 * c2 + 2 * N))
+    return out
+
+
 def mix2(a: T, b: Optional[T] = None, *, ka: float = 1.0, kb: float = 1.0, ca: Optional[T] = None,
          cb: Optional[T] = None, pa: Optional[T] = None, pb: Optional[T] = None, clamp01: bool = False,
          out: Optional[T] = None) -> T:
@@ -1083,7 +1108,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "cab_fused", "linear", "win_attn_fused", "token_projmlp", "token_linear_gated", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_front", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
+for _n in ("conv2d", "cab_fused", "sgfn_tail", "linear", "win_attn_fused", "token_projmlp", "token_linear_gated", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_front", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights", "chan_qkv_attn",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

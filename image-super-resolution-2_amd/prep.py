@@ -22,6 +22,16 @@ def pack_dw(w: T) -> T:
     return w.reshape(c, kh * kw).t().contiguous()
 
 
+def pack_sgfn_fc2(w2: T) -> T:
+    """fc2 [N, K] of ff_sgfn_tail -> bf16 tiles [ceil(K/32)][192][32] (tile c, row n, column kk = w2[n][32 c + kk]; zero padded)."""
+    n, k = w2.shape
+    assert n <= 192
+    ht = (k + 31) // 32
+    t = torch.zeros(192, ht * 32, device=w2.device, dtype=torch.float32)
+    t[:n, :k] = w2
+    return t.reshape(192, ht, 32).permute(1, 0, 2).contiguous().to(torch.bfloat16)
+
+
 def bn_scale_shift(sd: Dict[str, T], p: str, eps: float = 1e-5) -> Tuple[T, T]:
     """eval BatchNorm as y = x*scale + shift."""
     scale = sd[p + ".weight"] / torch.sqrt(sd[p + ".running_var"] + eps)

@@ -242,6 +242,15 @@ int ff_pool_vec_mlp(const float* part, int rows, int ld, float inv_count, int Ci
                     int act1, const float* W2, const float* b2, int Cout, int act2, float post, float* out, float* pooled_out,
                     void* stream);
 
+/* DAT SGFN tail in one launch (plain bf16 MFMA, fp32 accumulate; dat_arch.py:117-123, 163-170, 736):
+ *   out = res + W2 . ( h[:, :c2] * (dw3x3(LayerNorm(h[:, c2:2 c2])) + dw_bias) ) + b2
+ * h rows [B*H*W][ldh >= 2 c2] (fc1's output), stats [tokens][2] = (mean, rstd) of h[:, c2:2 c2] (ff_token_linear stats_out), gamma /
+ * beta [c2], dw_tapmajor [9][c2], fc2_tiles bf16 [hidden_tiles = ceil(c2/32)][192][32] (tile c, row n, column kk = W2[n][32 c + kk],
+ * zero padded; prep.pack_sgfn_fc2), N <= 192 outputs.  The zero padding of the convolution applies to the NORMALISED tensor. */
+int ff_sgfn_tail(const float* h, int ldh, int c2, const float* stats, const float* gamma, const float* beta,
+                 const float* dw_tapmajor, const float* dw_bias, const void* fc2_tiles, int hidden_tiles, const float* b2,
+                 const float* res, int ldr, float* out, int ldo, int B, int H, int W, int N, void* stream);
+
 /* Depth-wise conv, NHWC, zero padding, weights tap-major [KH*KW][C]:
  *   out = act((sum w*x + bias) * post_scale + post_shift) * mul_in[pixel][c]     (mul_in may be NULL)
  * dat_arch.py:109,403-407; nafnet_arch.py:78-81; large_kernel_attention.py:59-73; edge_enhancement.py:62. */

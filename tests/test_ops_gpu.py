@@ -1110,3 +1110,38 @@ def test_pool_vec_mlp_fused(dev, rows, C, Ch):
     x = rnd(1, 37, 29, C, dev=dev, seed=905)
     p2 = ops.pool_partials(x)
     close(p2.mean(), x.mean((1, 2)), 2e-6, "pool partials")
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (37, 45), (8, 32), (19, 70)])
+def test_sgfn_tail_fused(dev, H, W):
+    """DAT SGFN tail in one launch (dat_arch.py:117-123 SpatialGate, :163-170 fc2, :736 residual; plain bf16) against the PyTorch
+    fp32 chain: LayerNorm statistics from ff_token_linear's epilogue, zero padding AFTER the normalisation, ragged tiles."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_token_linear, pack_dw
+    C, Hd = 180, 720
+    c2 = Hd // 2
+    prev = ops.gemm_mode()
+    ops.set_gemm_mode("bf16")
+    try:
+        x = torch.empty(1, H, W, 192, device=dev)[..., :C]
+        x.copy_(rnd(1, H, W, C, dev=dev, seed=910, scale=1.5) + 0.3)
+        g, b = rnd(C, dev=dev, seed=911) * 0.1 + 1, rnd(C, dev=dev, seed=912) * 0.1
+        w1, b1 = rnd(Hd, C, dev=dev, seed=913, scale=1.0 / math.sqrt(C)), rnd(Hd, dev=dev, seed=914, scale=0.1)
+        g2, bb2 = rnd(c2, dev=dev, seed=915) * 0.1 + 1, rnd(c2, dev=dev, seed=916) * 0.1
+        wd, bd = rnd(c2, 1, 3, 3, dev=dev, seed=917, scale=0.3), rnd(c2, dev=dev, seed=918, scale=0.1)
+        w2, b2 = rnd(C, c2, dev=dev, seed=919, scale=1.0 / math.sqrt(c2)), rnd(C, dev=dev, seed=920, scale=0.1)
+        y, stats = ops.token_linear(x, pack_token_linear(w1, b1), gamma=g, beta=b, act="gelu", stats_range=(c2, Hd))
+        out = ops.sgfn_tail(y, c2, pack_dw(wd), bd, stats, g2, bb2, w2, b2, res=x)
+        # reference from the SAME fc1 output (the fused kernel is what is under test), fp64
+        yd = y.double()
+        x1, x2 = yd[..., :c2], yd[..., c2:]
+        x2n = F.layer_norm(x2, (c2,), g2.double(), bb2.double(), 1e-5).permute(0, 3, 1, 2)
+        gate = x1 * F.conv2d(x2n, wd.double(), bd.double(), padding=1, groups=c2).permute(0, 2, 3, 1)
+        ref = (x.double() + F.linear(gate, w2.double(), b2.double())).float()
+        close(out, ref, GEMM_TOL["bf16"], "sgfn tail")
+        # and against the two-launch bf16 path it replaces
+        z = ops.dwconv3x3_ln(y[..., c2:], pack_dw(wd), bd, stats, g2, bb2, mul_in=y[..., :c2])
+        two = ops.linear(z, w2, b2, res=x)
+        close(out, two, 4e-3, "sgfn tail vs two launches")
+    finally:
+        ops.set_gemm_mode(prev)
