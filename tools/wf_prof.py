@@ -1,4 +1,5 @@
-"""Single-kernel driver for rocprofv3 counter passes: runs ff_win_attn_fused (HAT geometry) a few times.  python3 tools/wf_prof.py [shift]"""
+"""Single-kernel driver for rocprofv3 counter passes: runs ff_win_attn_fused (HAT geometry) a few times.
+    python3 tools/wf_prof.py [shift] [mode = bf16 | bf16x3]"""
 import math
 import os
 import sys
@@ -13,6 +14,7 @@ dev = torch.device("cuda:0")
 H = W = 256
 C, heads, d, ws = 180, 6, 30, 16
 shift = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ops.set_gemm_mode(sys.argv[2] if len(sys.argv) > 2 else "bf16")
 g = torch.Generator().manual_seed(0)
 x = ops.empty_rows((1, H, W, C), dev)
 x.copy_(torch.randn(1, H, W, C, generator=g).to(dev))
