@@ -51,6 +51,7 @@ def _tl(blk: dict, key: str) -> dict:
     return pk
 
 
+_OCAB_V2 = os.environ.get("FF_OCAB_V2", "1") != "0"          # plain bf16: HAT's overlapping cross-attention in the persistent per-window kernel
 _SGFN_TAIL = os.environ.get("FF_SGFN_TAIL", "1") != "0"      # plain bf16: DAT's SpatialGate + fc2 + residual in one launch
 _CAB_FUSED = os.environ.get("FF_CAB_FUSED", "0") == "1"        # opt-in: HAT's conv branch in one launch (csrc/cab_fused.hip); bit-identical to the two launches, measured no faster
 
@@ -218,9 +219,13 @@ class HatHIP:
         else:
             qkv = ops.linear(ops.layernorm(x, *blk["n1"]), *blk["qkv"])
         att = ops.empty_like_rows(x)
-        ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
-                        kwin=(self.ows, self.ows), shift=(0, 0), use_mask=False, heads=self.heads, d=d, scale=d ** -0.5,
-                        rel_table=blk["rel"] if _REL_OCAB else None)
+        if _OCAB_V2 and ops.gemm_mode() == "bf16" and (self.ws, self.ows, d) == (16, 24, 30) and H % 16 == 0 and W % 16 == 0:
+            ops.ocab_attn(qkv, att, blk["rel"], q_off=0, k_off=C, v_off=2 * C, H=H, W=W, heads=self.heads, d=d, ws=self.ws, ows=self.ows,
+                          scale=d ** -0.5)                 # persistent per-window kernel, compact bias table in LDS (csrc/ocab_attn.hip)
+        else:
+            ops.window_attn(qkv, att, blk["bias"], q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W, win=(self.ws, self.ws),
+                            kwin=(self.ows, self.ows), shift=(0, 0), use_mask=False, heads=self.heads, d=d, scale=d ** -0.5,
+                            rel_table=blk["rel"] if _REL_OCAB else None)
         if _fast() and _PROJ_MLP:
             return ops.token_projmlp(att, x, _pm(blk), blk["n2"][0], blk["n2"][1])
         x = ops.token_linear(att, _tl(blk, "proj"), res=x) if _fast() else ops.linear(att, *blk["proj"], res=x)

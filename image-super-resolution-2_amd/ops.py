@@ -512,6 +512,23 @@ def window_attn(qkv: T, out: T, biasT: T, *, q_off: int, k_off: int, v_off: int,
     return out
 
 
+def ocab_attn(qkv: T, out: T, rel_rotated: T, *, q_off: int, k_off: int, v_off: int, o_off: int = 0, H: int, W: int, heads: int, d: int,
+              ws: int, ows: int, scale: float) -> T:
+    """HAT OCAB attention stage in one persistent-workgroup launch (plain bf16; csrc/ocab_attn.hip): 16x16 query windows against
+    24x24 zero-padded key windows, bias from the rotated compact table of prep.pack_rel_overlap [heads, 39*39]."""
+    if _GEMM_MODE != "bf16":
+        raise _lib.FFError("ocab_attn exists for the plain-bf16 contraction mode only")
+    qp, ldq, B, h_, w_, _ = _nhwc(qkv, "ocab_attn.qkv")
+    op, ldo, *_ = _nhwc(out, "ocab_attn.out")
+    if (h_, w_) != (H, W) or tuple(out.shape[:3]) != (B, H, W) or tuple(rel_rotated.shape) != (heads, (ws + ows - 1) ** 2) or not rel_rotated.is_contiguous():
+        raise _lib.FFError("ocab_attn: shape mismatch")
+    _lib.check(_L().ff_ocab_attn(qp, ldq, q_off, k_off, v_off, op, ldo, o_off, rel_rotated.data_ptr(), B, H, W, heads, d, ws, ows,
+                                 float(scale), _stream()))
+    nwin = B * (H // ws) * (W // ws)
+    _note(4.0 * nwin * heads * ws * ws * ows * ows * d, 4.0 * B * H * W * heads * d * 4)
+    return out
+
+
 def win_attn_fused(x: T, out: T, pk: dict, rel_padded: T, *, gamma: Optional[T], beta: Optional[T], eps: float = 1e-5,
                    H: int, W: int, Hp: int, Wp: int, win: Tuple[int, int], shift: Tuple[int, int], use_mask: bool,
                    head0: int = 0, nheads: Optional[int] = None, o_off: int = 0, zero_pad: bool = False,
@@ -1108,7 +1125,7 @@ def tile_normalize(acc: T, wsum: T):
     _lib.check(_L().ff_tile_normalize(acc.data_ptr(), wsum.data_ptr(), C, H, W, _stream()))
 
 
-for _n in ("conv2d", "cab_fused", "sgfn_tail", "linear", "win_attn_fused", "token_projmlp", "token_linear_gated", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_front", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
+for _n in ("conv2d", "cab_fused", "sgfn_tail", "ocab_attn", "linear", "win_attn_fused", "token_projmlp", "token_linear_gated", "token_mlp", "token_linear", "pixel_mlp", "dwconv3_gate_pool", "naf_front", "naf_ffn", "window_attn", "layernorm", "pool_mean", "vec_mlp", "dwconv2d", "dwconv3x3_ln", "mix2", "fma3", "affine",
            "nchw_to_nhwc", "nhwc_to_nchw", "resize", "avgpool2", "dct8_bands", "dwt_pass", "fft_bands", "chan_attn_weights", "chan_qkv_attn",
            "band_mha_core", "band_weight", "freq_guidance", "dynamic_gates", "fuse_blend", "tile_accum", "tile_normalize"):
     globals()[_n] = _instrument(globals()[_n])

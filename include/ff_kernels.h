@@ -242,6 +242,14 @@ int ff_pool_vec_mlp(const float* part, int rows, int ld, float inv_count, int Ci
                     int act1, const float* W2, const float* b2, int Cout, int act2, float post, float* out, float* pooled_out,
                     void* stream);
 
+/* HAT OCAB attention stage (hat_arch.py:392-438), plain bf16 MFMA: softmax(q k^T * scale + bias) v for 16x16 query windows against
+ * the 24x24 key windows of nn.Unfold(kernel 24, stride 16, padding 4) -- keys outside the image are zero vectors that still take
+ * part in the softmax.  qkv rows [B*H*W][ldq] hold q / k / v at q_off / k_off / v_off + head * 30; rel_rotated [heads][39*39] is the
+ * relative_position_bias_table rotated as prep.pack_rel_overlap does (the reference gathers it with negative, wrapped indices).
+ * One persistent workgroup per window; built for ws = 16, ows = 24, d = 30 (anything else: ff_window_attn_bf16s). */
+int ff_ocab_attn(const float* qkv, int ldq, int q_off, int k_off, int v_off, float* out, int ldo, int o_off,
+                 const float* rel_rotated, int B, int H, int W, int heads, int d, int ws, int ows, float scale, void* stream);
+
 /* DAT SGFN tail in one launch (plain bf16 MFMA, fp32 accumulate; dat_arch.py:117-123, 163-170, 736):
  *   out = res + W2 . ( h[:, :c2] * (dw3x3(LayerNorm(h[:, c2:2 c2])) + dw_bias) ) + b2
  * h rows [B*H*W][ldh >= 2 c2] (fc1's output), stats [tokens][2] = (mean, rstd) of h[:, c2:2 c2] (ff_token_linear stats_out), gamma /

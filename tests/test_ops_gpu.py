@@ -1145,3 +1145,39 @@ def test_sgfn_tail_fused(dev, H, W):
         close(out, two, 4e-3, "sgfn tail vs two launches")
     finally:
         ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("H,W", [(32, 32), (48, 80), (256, 256)])
+def test_ocab_attn_persistent(dev, H, W):
+    """HAT OCAB attention in the persistent per-window kernel (hat_arch.py:392-438; plain bf16) against the unfold-based torch chain:
+    zero keys outside the image still enter the softmax, bias through the reference's wrapped (negative) table indices."""
+    from isr2_amd import ops
+    from isr2_amd.prep import pack_rel_overlap
+    from oracle import freqfusion_oracle as O
+    heads, d, ws, ows, C = 6, 30, 16, 24, 180
+    prev = ops.gemm_mode()
+    ops.set_gemm_mode("bf16")
+    try:
+        qkv = rnd(1, H, W, 3 * C, dev=dev, seed=930)
+        table = rnd((ws + ows - 1) ** 2, heads, dev=dev, seed=931, scale=0.5)
+        bias = _hat_bias(table, ws, ows, heads)
+        out = ops.empty_rows((1, H, W, C), dev)
+        out.zero_()
+        ops.ocab_attn(qkv, out, pack_rel_overlap(table, ws, ows), q_off=0, k_off=C, v_off=2 * C, H=H, W=W, heads=heads, d=d, ws=ws, ows=ows,
+                      scale=d ** -0.5)
+        q = O._win_split(qkv[..., :C], ws, ws)
+        kv = qkv[..., C:].permute(0, 3, 1, 2)
+        nwin = (H // ws) * (W // ws)
+        kvw = F.unfold(kv, kernel_size=ows, stride=ws, padding=(ows - ws) // 2)
+        kvw = kvw.reshape(1, 2, C, ows * ows, nwin).permute(1, 0, 4, 3, 2).reshape(2, nwin, ows * ows, C)
+        qh = q.reshape(-1, ws * ws, heads, d).transpose(1, 2) * d ** -0.5
+        kh = kvw[0].reshape(-1, ows * ows, heads, d).transpose(1, 2)
+        vh = kvw[1].reshape(-1, ows * ows, heads, d).transpose(1, 2)
+        o = O._softmax_attn(qh, kh, vh, bias, None).transpose(1, 2).reshape(-1, ws * ws, C)
+        close(out, O._win_merge(o, ws, ws, H, W), GEMM_TOL["bf16"], "ocab persistent")
+        two = torch.zeros(1, H, W, C, device=dev)
+        ops.window_attn(qkv, two, bias.transpose(1, 2).contiguous(), q_off=0, k_off=C, v_off=2 * C, o_off=0, H=H, W=W, Hp=H, Wp=W,
+                        win=(ws, ws), kwin=(ows, ows), shift=(0, 0), use_mask=False, heads=heads, d=d, scale=d ** -0.5)
+        close(out, two, 4e-3, "ocab persistent vs two-stage kernel")
+    finally:
+        ops.set_gemm_mode(prev)
