@@ -59,7 +59,7 @@ template <int NTERMS> struct HaloGeom {
   static constexpr int PROW = NTERMS == 1 ? 2816 : HX_PROW;        // bytes per halo-tile row of 18 pixels
 };
 template <int WM, int WN, int MI, int NI, int WK, int ACT, int NSLOT, int NTERMS>
-__global__ __launch_bounds__(WM * WN * 64, (NTERMS == 1 && MI * NI <= 2 && WM * WN == 8) ? 4 : (NTERMS == 1 && MI * NI <= 2 && WM * WN == 4 && WM == 4) ? 3 : 1)
+__global__ __launch_bounds__(WM * WN * 64, (NTERMS == 1 && MI * NI <= 2 && WM * WN == 8) ? 4 : (NTERMS == 1 && MI * NI <= 2 && WM * WN == 4 && WM == 4) ? 3 : (NTERMS == 1 && MI * NI == 6 && WM * WN == 4) ? 2 : 1)
 void conv3x3_halo_kernel(HaloParams p) {
   constexpr int ROWB = HaloGeom<NTERMS>::ROWB, PROW = HaloGeom<NTERMS>::PROW;
   constexpr int NW = WM * WN, NT = NW * 64;            // 4 or 8 waves
@@ -70,7 +70,8 @@ void conv3x3_halo_kernel(HaloParams p) {
   constexpr int XBYTES = (TH + 2) * PROW;
   constexpr int WROW = (NTERMS == 1 ? WK * 2 : WK * 4) + 16, NH = 64 / WK, KSTEPS = WK / 16;
   constexpr bool TWO_PER_CU = NTERMS == 1 && MI * NI <= 2 && WM * WN == 8;   // 128-register budget: the partner workgroup hides the chunk load instead
-  constexpr bool XPREF = MI * NI <= 6 && !TWO_PER_CU;   // prefetch the next chunk's input rows into registers during tap 7
+  constexpr bool PAIR_4W = NTERMS == 1 && MI * NI == 6 && WM * WN == 4;      // 8 x 16 pixels x 192: two 4-wave workgroups per CU, 256 registers
+  constexpr bool XPREF = MI * NI <= 6 && !TWO_PER_CU && !PAIR_4W;   // prefetch the next chunk's input rows into registers during tap 7
   constexpr int WPIECES = (BN * WROW + 1023) / 1024, WSLOT = WPIECES * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Xs = smem;
@@ -342,7 +343,8 @@ extern "C" long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn, int
 // one 16-row workgroup per CU the launch is as long as ONE workgroup's serial load / taps / store sequence.
 static int halo_rows_per_wg(int B, int H, int W, int Cout, int bn, int nterms) {
   if (bn == 128) return 8;
-  if (nterms == 1 && bn <= 64) {
+  static const int wide8 = []() { const char* e = getenv("FF_HALO_192_8ROW"); return e ? atoi(e) : 0; }();   // tuning switch: 8-row form for 192 outputs (measured 36.9 vs 35.8 us on CAB 60->180, 67.1 vs 65.7 on 180->180: off)
+  if (nterms == 1 && (bn <= 64 || (bn == 192 && wide8))) {
     const long long tiles16 = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + bn - 1) / bn);
     if (tiles16 < 512) return 8;
   }
@@ -381,6 +383,8 @@ extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int 
     if (ring == 5) return launch_halo<4, 1, 1, 2, 64, 5, 1>(p, st);
     return launch_halo<4, 1, 1, 2, 64, 2, 1>(p, st);
   }
+  if (nterms == 1 && bn == 192 && halo_rows_per_wg(B, H, W, Cout, bn, nterms) == 8)
+    return launch_halo<2, 2, 2, 3, 32, 2, 1>(p, st);      // 8x16 pixels x 192, 4 waves, 58 KB: two workgroups per CU on the 256 x 256 grids
   if (nterms == 1 && bn == 64 && ring == 3) return launch_halo<8, 1, 1, 2, 64, 3, 1>(p, st);
   if (nterms == 1 && bn == 192 && ring >= 3) return launch_halo<4, 2, 2, 3, 32, 3, 1>(p, st);
   switch (bn) {
