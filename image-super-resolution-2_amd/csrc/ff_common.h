@@ -60,6 +60,23 @@ __device__ __forceinline__ float ff_gelu_fast(float v) {
   return 0.5f * v * (1.0f + er);
 }
 
+// Plain-bf16 kernels only: GELU as x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3) -- |error| <= 4.8e-4 against the erf form, a
+// sixteenth of the bf16 rounding the value (or the product it enters) receives next.  Two values at a time: the packed fp32
+// multiply / fma / add take both in one instruction; 5 full-rate + 2 transcendental operations per value instead of 14 + 2.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 ff_gelu_sig2(f32x2 x) {
+  const float A = -2.3022081f, B = -0.10294324f;       // -2 sqrt(2/pi) log2(e) * {1, 0.044715}
+  const f32x2 x2 = x * x;
+  const f32x2 pz = x2 * B + A;
+  const f32x2 z = x * pz;
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(z[0]); e[1] = __builtin_amdgcn_exp2f(z[1]);
+  const f32x2 d = e + 1.0f;
+  f32x2 r;
+  r[0] = __builtin_amdgcn_rcpf(d[0]); r[1] = __builtin_amdgcn_rcpf(d[1]);
+  return x * r;
+}
+
 __device__ __forceinline__ float ff_act_fast(float v, int act) { return act == ACT_GELU ? ff_gelu_fast(v) : ff_act(v, act); }
 
 // compile-time activation (epilogues dispatch ONCE per kernel on the runtime code, not once per element:

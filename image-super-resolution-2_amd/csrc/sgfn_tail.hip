@@ -17,7 +17,6 @@
 #include "ff_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define SG_TH 8
 #define SG_TW 32

@@ -36,6 +36,9 @@ struct TokenLinParams {
 
 // NTERMS = 3: split-bf16 products hi*lo + lo*hi + hi*hi (fp32-grade); NTERMS = 1: plain bf16 (hi*hi only: a third of the MFMAs, no lo
 // fragments built or read; the weight image keeps its lo plane, unused).
+#ifndef TL_GELU_SIG
+#define TL_GELU_SIG 1
+#endif
 template <int ACT, int TL_KS, bool VEC4, bool GATED = false, int NTERMS = 3>
 __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
   constexpr int TL_SLOTS = 2 * TL_KS + 1, TL_ROWB = TL_SLOTS * 16, TL_PL = 32 * TL_SLOTS, TL_PIECES = 2 * TL_PL / 64;
@@ -316,8 +319,13 @@ __global__ __launch_bounds__(512) void token_linear_kernel(TokenLinParams p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 v4;
+      if (ACT == ACT_GELU && NTERMS == 1 && TL_GELU_SIG) {      // plain bf16: the sigmoid form (ff_common.h)
+        const f32x2 ga = ff_gelu_sig2((f32x2){acc[4 * g], acc[4 * g + 1]}), gb = ff_gelu_sig2((f32x2){acc[4 * g + 2], acc[4 * g + 3]});
+        v4 = (f32x4){ga[0], ga[1], gb[0], gb[1]};
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v4[e] = ff_act_c<ACT, true>(acc[4 * g + e]);
+        for (int e = 0; e < 4; ++e) v4[e] = ff_act_c<ACT, true>(acc[4 * g + e]);
+      }
       *reinterpret_cast<f32x4*>(tr + l31 * TL_TR + 8 * g + 4 * hh) = v4;
       if (p.stats) {
         const int c0 = nt * 32 + 8 * g + 4 * hh;

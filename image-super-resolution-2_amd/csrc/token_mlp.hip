@@ -672,22 +672,6 @@ __global__ __launch_bounds__(512) void token_projmlp_kernel(TokenProjMlpParams p
 #define PM_OFF_PATCH PM_PROJB
 #define PM_OFF_VEC (PM_OFF_PATCH + 8 * PM_PATCHB)
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// two GELUs at a time (the packed fp32 multiply / fma / add take both lanes of the pair in one instruction)
-__device__ __forceinline__ f32x2 ff_gelu_sig2(f32x2 x) {
-  const float A = -2.3022081f, B = -0.10294324f;       // -2 sqrt(2/pi) log2(e) * {1, 0.044715}
-  const f32x2 x2 = x * x;
-  const f32x2 pz = x2 * B + A;
-  const f32x2 z = x * pz;
-  f32x2 e;
-  e[0] = __builtin_amdgcn_exp2f(z[0]); e[1] = __builtin_amdgcn_exp2f(z[1]);
-  const f32x2 d = e + 1.0f;
-  f32x2 r;
-  r[0] = __builtin_amdgcn_rcpf(d[0]); r[1] = __builtin_amdgcn_rcpf(d[1]);
-  return x * r;
-}
-
 __global__ __launch_bounds__(512) void token_projmlp_bf16_kernel(TokenProjMlpParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Gs = reinterpret_cast<float*>(smem + PM_OFF_VEC);
