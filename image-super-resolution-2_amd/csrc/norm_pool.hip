@@ -283,36 +283,44 @@ __global__ __launch_bounds__(1024) void pool_vec_mlp_kernel(const float* __restr
                                                             const float* __restrict__ W2, const float* __restrict__ b2, int Cout, int act2,
                                                             float post, float* __restrict__ out, float* __restrict__ pooled) {
   extern __shared__ float sm[];
-  float* red = sm;                       // [16][64]
-  float* xin = sm + 16 * 64;             // [Cin]
+  float* red = sm;                       // [16][CP]  (CP = Cin rounded up to 64)
+  const int CP = (Cin + 63) & ~63;
+  float* xin = sm + 16 * CP;             // [Cin]
   float* hid = xin + Cin;                // [Ch]
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  for (int c0 = 0; c0 < Cin; c0 += 64) {
-    const int c = c0 + lane;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (c < Cin) {
-      const float* pp = part + c;
-      int r = rg;
-      for (; r + 48 < rows; r += 64) {
-        s0 += pp[(long long)r * ld];
-        s1 += pp[(long long)(r + 16) * ld];
-        s2 += pp[(long long)(r + 32) * ld];
-        s3 += pp[(long long)(r + 48) * ld];
-      }
-      for (; r < rows; r += 16) s0 += pp[(long long)r * ld];
-    }
-    red[rg * 64 + lane] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (rg == 0 && c < Cin) {
-      float t = 0.f;
+  // every 64-channel chunk of the row group's partial sums is accumulated in the same pass (independent loads in flight for all of
+  // them), one barrier for the whole reduction
+  for (int c0 = 0; c0 < CP; c0 += 256) {
+    float s[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    int r = rg;
+    for (; r + 16 < rows; r += 32) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) t += red[k * 64 + lane];
-      t *= inv;
-      xin[c] = t;
-      if (pooled) pooled[c] = t;
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + 64 * k + lane;
+        if (c < Cin) { s[k][0] += part[(long long)r * ld + c]; s[k][1] += part[(long long)(r + 16) * ld + c]; }
+      }
     }
-    __syncthreads();
+    for (; r < rows; r += 16) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + 64 * k + lane;
+        if (c < Cin) s[k][0] += part[(long long)r * ld + c];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (c0 + 64 * k < CP) red[rg * CP + c0 + 64 * k + lane] = s[k][0] + s[k][1];
   }
+  __syncthreads();
+  for (int c = threadIdx.x; c < Cin; c += 1024) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k * CP + c];
+    t *= inv;
+    xin[c] = t;
+    if (pooled) pooled[c] = t;
+  }
+  __syncthreads();
   for (int j = rg; j < Ch; j += 16) {
     float s = 0.f;
     for (int i = lane; i < Cin; i += 64) s += W1[(long long)j * Cin + i] * xin[i];
@@ -331,8 +339,8 @@ extern "C" int ff_pool_vec_mlp(const float* part, int rows, int ld, float inv_co
                                int act1, const float* W2, const float* b2, int Cout, int act2, float post, float* out,
                                float* pooled_out, void* stream) {
   FF_CHECK_ARG(part && W1 && W2 && out, "ff_pool_vec_mlp: null pointer");
-  FF_CHECK_ARG(rows > 0 && Cin > 0 && ld >= Cin && Ch > 0 && Ch <= 64 && Cout > 0 && Cin <= 4096, "ff_pool_vec_mlp: bad dims (hidden width <= 64)");
-  hipLaunchKernelGGL(pool_vec_mlp_kernel, dim3(1), dim3(1024), (size_t)(16 * 64 + Cin + Ch) * 4, (hipStream_t)stream, part, rows, ld,
+  FF_CHECK_ARG(rows > 0 && Cin > 0 && ld >= Cin && Ch > 0 && Ch <= 64 && Cout > 0 && Cin <= 512, "ff_pool_vec_mlp: bad dims (Cin <= 512, hidden width <= 64)");
+  hipLaunchKernelGGL(pool_vec_mlp_kernel, dim3(1), dim3(1024), (size_t)(16 * ((Cin + 63) & ~63) + Cin + Ch) * 4, (hipStream_t)stream, part, rows, ld,
                      inv_count, Cin, W1, b1, Ch, act1, W2, b2, Cout, act2, post, out, pooled_out);
   FF_LAUNCH_CHECK("ff_pool_vec_mlp");
   return FF_OK;

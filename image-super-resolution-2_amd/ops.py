@@ -729,7 +729,7 @@ def vec_mlp(v, W1: T, b1: Optional[T], act1, W2: Optional[T] = None, b2: Optiona
     """act2(W2 . act1(W1 . v + b1) + b2) * post per row of v [B, Cin] (W2 None: one layer).  v may be a PoolPartials: the pool is
     then finished inside the same launch (two-layer form with a hidden width <= 64), otherwise finished first."""
     if isinstance(v, PoolPartials):
-        if W2 is not None and W1.shape[0] <= 64 and _POOL_MLP:
+        if W2 is not None and W1.shape[0] <= 64 and v.C <= 512 and _POOL_MLP:
             if W1.shape[1] != v.C or W2.shape[1] != W1.shape[0]:
                 raise _lib.FFError("vec_mlp: weight shape mismatch")
             out = torch.empty((1, W2.shape[0]), device=v.part.device, dtype=torch.float32)
