@@ -290,26 +290,27 @@ __global__ __launch_bounds__(1024) void pool_vec_mlp_kernel(const float* __restr
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
   // every 64-channel chunk of the row group's partial sums is accumulated in the same pass (independent loads in flight for all of
   // them), one barrier for the whole reduction
+  // a single workgroup is latency bound: the loads of eight rows x four 64-channel chunks are issued before any is consumed
+  // (one L2 round trip per 32 loads instead of one per row)
   for (int c0 = 0; c0 < CP; c0 += 256) {
-    float s[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    int r = rg;
-    for (; r + 16 < rows; r += 32) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = rg; r0 < rows; r0 += 128) {
+      float v[8][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = c0 + 64 * k + lane;
-        if (c < Cin) { s[k][0] += part[(long long)r * ld + c]; s[k][1] += part[(long long)(r + 16) * ld + c]; }
-      }
-    }
-    for (; r < rows; r += 16) {
+      for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = c0 + 64 * k + lane;
-        if (c < Cin) s[k][0] += part[(long long)r * ld + c];
-      }
+        for (int k = 0; k < 4; ++k) {
+          const int r = r0 + 16 * j, c = c0 + 64 * k + lane;
+          v[j][k] = (r < rows && c < Cin) ? part[(long long)r * ld + c] : 0.f;
+        }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += v[j][k];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (c0 + 64 * k < CP) red[rg * CP + c0 + 64 * k + lane] = s[k][0] + s[k][1];
+      if (c0 + 64 * k < CP) red[rg * CP + c0 + 64 * k + lane] = s[k];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < Cin; c += 1024) {
