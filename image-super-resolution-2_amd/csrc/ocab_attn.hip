@@ -31,7 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define OC_RELB (1536 * 4)
 #define OC_OFF_TOK (OC_OFF_REL + 2 * OC_RELB)
 #define OC_LDS (OC_OFF_TOK + OC_NK * 4)
-#define OC_NLOAD 17                       // ceil(288 keys x 30 float2 / 512 threads)
+#define OC_NLOAD 18                       // 288 keys / 16 keys per pass
 
 struct OcabParams {
   const float* qkv; float* out; const float* rel;
@@ -85,35 +85,35 @@ __global__ __launch_bounds__(512) void ocab_attn_kernel(OcabParams p) {
   const int rel_lane = 600 - OC_RELW * qy - qx + 4 * hh;
   const float LOG2E = 1.4426950408889634f;
 
-  // ---- staging: float2 number tid + 512 i of a stage = (key idx / 30, pair idx % 30; pairs 0..14 are k, 15..29 are v) ------------
+  // ---- staging: lane & 31 = float2 pair of a key's head slice (0..14 k, 15..29 v, 30 / 31 idle), (tid >> 5) + 16 i = key of the stage:
+  //      no per-element index arithmetic, a wave instruction fetches the four 120-byte k / v segments of two keys --------------------
+  const int spr = tid & 31, skey = tid >> 5;
+  const bool s_on = spr < 30, s_isk = spr < 15;
+  const int s_ch = s_isk ? p.k_off + 2 * spr : p.v_off + 2 * (spr - 15);
   float2 stg[OC_NLOAD];
   float tb[3];
   float2 qn[8];
   auto stage_load = [&](int h, int st) {
 #pragma unroll
     for (int i = 0; i < OC_NLOAD; ++i) {
-      const int idx = tid + 512 * i;
-      const int kl = idx / 30, pr = idx - 30 * kl;
-      const int tk = idx < OC_STK * 30 ? ktok[st * OC_STK + kl] : -1;
-      const int ch = (pr < 15 ? p.k_off + 2 * pr : p.v_off + 2 * (pr - 15)) + h * 30;
-      const float2 u = *reinterpret_cast<const float2*>(p.qkv + (tk >= 0 ? (long long)tk * p.ldq + ch : 0));
+      const int tk = s_on ? ktok[st * OC_STK + skey + 16 * i] : -1;
+      const float2 u = *reinterpret_cast<const float2*>(p.qkv + (tk >= 0 ? (long long)tk * p.ldq + s_ch + h * 30 : 0));
       stg[i] = tk >= 0 ? u : (float2){0.f, 0.f};
     }
   };
   auto stage_store = [&](int buf) {
     unsigned char* kb = smem + buf * OC_STAGEB;
     unsigned char* vb = kb + OC_KBUF;
+    if (s_on) {
 #pragma unroll
-    for (int i = 0; i < OC_NLOAD; ++i) {
-      const int idx = tid + 512 * i;
-      if (idx < OC_STK * 30) {
-        const int kl = idx / 30, pr = idx - 30 * kl;
+      for (int i = 0; i < OC_NLOAD; ++i) {
+        const int kl = skey + 16 * i;
         const __bf16 a = (__bf16)stg[i].x, c = (__bf16)stg[i].y;
-        if (pr < 15) {
+        if (s_isk) {
           const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, c) << 16);
-          *reinterpret_cast<unsigned*>(kb + kl * OC_KROWB + 4 * pr) = pk;
+          *reinterpret_cast<unsigned*>(kb + kl * OC_KROWB + 4 * spr) = pk;
         } else {
-          const int ch = 2 * (pr - 15), pos = oc_swap23(kl);
+          const int ch = 2 * (spr - 15), pos = oc_swap23(kl);
           *reinterpret_cast<__bf16*>(vb + ch * OC_VROWB + 2 * pos) = a;
           *reinterpret_cast<__bf16*>(vb + (ch + 1) * OC_VROWB + 2 * pos) = c;
         }
