@@ -246,3 +246,23 @@ def test_whole_image_510x339_against_reference_golden(model):
             assert dc < tol, (how, c, int(y), int(x), dc)
         l2 = float(torch.sqrt((out.double() ** 2).sum()))
         assert abs(l2 - float(g["stats"][2])) <= 1e-5 * float(g["stats"][2])
+
+
+def test_plain_bf16_whole_image_510x339(model_bf16):
+    """The plain-bf16 kernels (persistent OCAB attention, rescheduled window attention / proj + MLP, SGFN tail) on the whole 510x339
+    image: 172 890 tokens, reflect pad to 512x352 in HAT / DAT, ragged 8x32 tiles in the SGFN tail -- against the reference's forward
+    (tests/golden/whole510_339.npz) at the bf16 bar."""
+    g = np.load(os.path.join(GOLD, "whole510_339.npz"))
+    lr = torch.from_numpy(g["lr"]).cuda()
+    tol, min_psnr = BF16_BAR
+    out = model_bf16(lr).cpu()
+    assert tuple(out.shape) == (1, 3, 1356, 2040)
+    got = out.reshape(-1)[torch.from_numpy(g["big/idx"])]
+    ref = torch.from_numpy(g["big/val"])
+    d = (got - ref).abs().max().item()
+    psnr = _psnr_from_samples(got, ref)
+    print("whole510 bf16: max|d| over 65536 samples =", d, "PSNR =", psnr)
+    assert d < tol and psnr >= min_psnr
+    for c, (y, x) in enumerate(g["crop_corners"]):
+        dc = (out[0, :, y:y + 64, x:x + 64] - torch.from_numpy(g["crops"][c])).abs().max().item()
+        assert dc < tol, (c, int(y), int(x), dc)
