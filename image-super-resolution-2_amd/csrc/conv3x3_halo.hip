@@ -20,7 +20,16 @@ struct HaloParams {
   int B, H, W, Cin, ldi, Cout, ldo, ldr, nchunk, tiles_x, tiles_y, nblk, act, shuffle;
   float alpha;
   float* pool_part;   // optional [workgroups][Cout padded to nblk*BN]: per-workgroup channel sums of the stored values
+#ifdef HX_TIMING
+  unsigned long long* dbg;   // tools/hx_time.cpp: [block][wave][8] wall-clock stamps (debug build only)
+#endif
 };
+#ifdef HX_TIMING
+static unsigned long long* g_hx_dbg = nullptr;
+#define HX_T(i) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define HX_T(i) do { } while (0)
+#endif
 
 #define HX_ROW 272
 #define HX_W 18
@@ -59,7 +68,7 @@ template <int NTERMS> struct HaloGeom {
   static constexpr int PROW = NTERMS == 1 ? 2816 : HX_PROW;        // bytes per halo-tile row of 18 pixels
 };
 template <int WM, int WN, int MI, int NI, int WK, int ACT, int NSLOT, int NTERMS>
-__global__ __launch_bounds__(WM * WN * 64, (NTERMS == 1 && MI * NI <= 2 && WM * WN == 8) ? 4 : (NTERMS == 1 && MI * NI <= 2 && WM * WN == 4 && WM == 4) ? 3 : (NTERMS == 1 && MI * NI == 6 && WM * WN == 4) ? 2 : 1)
+__global__ __launch_bounds__(WM * WN * 64, (NTERMS == 1 && MI * NI <= 2 && WM * WN == 8 && NSLOT != 9) ? 4 : (NTERMS == 1 && MI * NI <= 2 && WM * WN == 4 && WM == 4) ? 3 : (NTERMS == 1 && MI * NI == 6 && WM * WN == 4) ? 2 : 1)
 void conv3x3_halo_kernel(HaloParams p) {
   constexpr int ROWB = HaloGeom<NTERMS>::ROWB, PROW = HaloGeom<NTERMS>::PROW;
   constexpr int NW = WM * WN, NT = NW * 64;            // 4 or 8 waves
@@ -69,7 +78,8 @@ void conv3x3_halo_kernel(HaloParams p) {
   constexpr int BN = WN * NI * 32, TN = NI * 32;
   constexpr int XBYTES = (TH + 2) * PROW;
   constexpr int WROW = (NTERMS == 1 ? WK * 2 : WK * 4) + 16, NH = 64 / WK, KSTEPS = WK / 16;
-  constexpr bool TWO_PER_CU = NTERMS == 1 && MI * NI <= 2 && WM * WN == 8;   // 128-register budget: the partner workgroup hides the chunk load instead
+  constexpr bool BLK = NSLOT == 9;           // blocked schedule: a chunk's nine weight tiles resident, two barriers per chunk (below)
+  constexpr bool TWO_PER_CU = NTERMS == 1 && MI * NI <= 2 && WM * WN == 8 && !BLK;   // 128-register budget: the partner workgroup hides the chunk load instead
   constexpr bool PAIR_4W = NTERMS == 1 && MI * NI == 6 && WM * WN == 4;      // 8 x 16 pixels x 192: two 4-wave workgroups per CU, 256 registers
   constexpr bool XPREF = MI * NI <= 6 && !TWO_PER_CU && !PAIR_4W;   // prefetch the next chunk's input rows into registers during tap 7
   constexpr int WPIECES = (BN * WROW + 1023) / 1024, WSLOT = WPIECES * 1024;
@@ -104,6 +114,7 @@ void conv3x3_halo_kernel(HaloParams p) {
     }
   };
   const int ntiles = p.nchunk * 9 * NH;
+  HX_T(0);
   // Ring of NSLOT weight slots, DEPTH = NSLOT - 1 tiles in flight: tile T + DEPTH is issued at the top of tile T (into the slot tile T - 1
   // just vacated) and waited for DEPTH tiles later with a COUNTED s_waitcnt vmcnt(NPMIN * (DEPTH - 1)) (NPMIN = the fewest pieces any wave
   // issues per tile; waves that issue one more over-wait by a piece: vmcnt retires in issue order) followed by a RAW s_barrier.
@@ -112,9 +123,14 @@ void conv3x3_halo_kernel(HaloParams p) {
   // (~0.7 us against 0.12 us of MFMA work per tap in plain bf16).
   constexpr int DEPTH = NSLOT - 1;
   constexpr int NPMIN = WPIECES / NW;
+  if constexpr (BLK) {
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d)
-    if (d < ntiles) dma(d, d);
+    for (int tp = 0; tp < 5; ++tp) dma(tp, tp);
+  } else {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (d < ntiles) dma(d, d);
+  }
 
   // ---- input halo staging: 16 lanes (float4 each) per pixel, 16 pixels per pass ---------------------------------
   const int cq = (tid & 15) * 4, prow = tid >> 4;
@@ -159,6 +175,7 @@ void conv3x3_halo_kernel(HaloParams p) {
   };
   load_x(0);
   store_x();
+  HX_T(1);
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -175,56 +192,107 @@ void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll
   for (int j = 0; j < NI; ++j) boff[j] = (wc * TN + j * 32 + l31) * WROW + 16 * hh;
 
-  int T = 0;
-  for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap - 3 * dy;
-      const unsigned char* xa = Xs + dy * PROW + dx * ROWB;
+  // one tap of the current chunk from weight slot `slot` (all KSTEPS k-steps)
+  auto tap_mfma = [&](int tap, int slot) {
+    const int dy = tap / 3, dx = tap - 3 * dy;
+    const unsigned char* xa = Xs + dy * PROW + dx * ROWB;
+    const unsigned char* wb = Ws + slot * WSLOT;
+    // every operand of the tap is requested before the first MFMA: 12 ds_read_b128 in flight instead of 3 per k-step
+    bf16x8 ah[KSTEPS][MI], bh[KSTEPS][NI];
 #pragma unroll
-      for (int half = 0; half < NH; ++half, ++T) {
-        // own DMA pieces of tile T have landed (counted wait: the younger tiles stay in flight); LDS writes of this wave (the staged
-        // input tile) are complete; the barrier then makes every wave's pieces and the input tile visible, and guarantees the slot of
-        // tile T - 1 is no longer being read
-        if (T + DEPTH - 1 < ntiles) halo_wait_vmcnt<NPMIN * (DEPTH - 1)>();
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int s = 0; s < KSTEPS; ++s) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) ah[s][i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * s);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bh[s][j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s);
+    }
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+  };
+  if constexpr (BLK) {
+    // Blocked schedule (plain bf16, 64-channel weight tiles, one workgroup per CU): the nine tap tiles of a chunk have fixed slots; taps
+    // 0..4 are computed while taps 5..8 land, taps 5..8 while the next chunk's 0..4 (and its input rows, in registers) land -- three
+    // barriers per chunk instead of nine, 40 / 32 MFMAs per wave between them instead of 8 (tools/hx_time.cpp: 0.7 us per tap of the
+    // ring form against 0.1 us of MFMA issue).
+    static_assert(NTERMS == 1 && NH == 1, "blocked schedule: plain bf16, one weight tile per tap");
+    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // taps 0..4 and the input tile of this chunk are in LDS
+#pragma unroll
+      for (int tp = 5; tp < 9; ++tp) dma(chunk * 9 + tp, tp);
+#pragma unroll
+      for (int tp = 0; tp < 5; ++tp) tap_mfma(tp, tp);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // taps 5..8 landed; slots 0..4 are free
+      if (chunk + 1 < p.nchunk) {
+#pragma unroll
+        for (int tp = 0; tp < 5; ++tp) dma((chunk + 1) * 9 + tp, tp);
+        load_x(chunk + 1);
+      }
+#pragma unroll
+      for (int tp = 5; tp < 9; ++tp) tap_mfma(tp, tp);
+      if (chunk + 1 < p.nchunk) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (T + DEPTH < ntiles) dma(T + DEPTH, (T + DEPTH) % NSLOT);
-        if (XPREF && tap == 7 && half == NH - 1 && chunk + 1 < p.nchunk) load_x(chunk + 1);
-        const unsigned char* wb = Ws + (T % NSLOT) * WSLOT;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-          bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
-#pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            ah[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * (half * KSTEPS + s));
-            if (NTERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * (half * KSTEPS + s) + 128);
-          }
-#pragma unroll
-          for (int j = 0; j < NI; ++j) {
-            bh[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s);
-            if (NTERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s + WK * 2);
-          }
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-              if (NTERMS == 3) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-              }
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-            }
-        }
+        __builtin_amdgcn_s_barrier();                     // every wave is done reading this chunk's input tile
+        store_x();
       }
     }
-    if (chunk + 1 < p.nchunk) {
-      __syncthreads();                 // every wave is done reading this chunk's input tile
-      if (!XPREF) load_x(chunk + 1);   // big-accumulator configuration: no registers to hold the prefetch across the taps
-      store_x();                       // (made visible by the barrier at the top of the next tap)
+  } else {
+  int T = 0;
+    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        const unsigned char* xa = Xs + dy * PROW + dx * ROWB;
+  #pragma unroll
+        for (int half = 0; half < NH; ++half, ++T) {
+          // own DMA pieces of tile T have landed (counted wait: the younger tiles stay in flight); LDS writes of this wave (the staged
+          // input tile) are complete; the barrier then makes every wave's pieces and the input tile visible, and guarantees the slot of
+          // tile T - 1 is no longer being read
+          if (T + DEPTH - 1 < ntiles) halo_wait_vmcnt<NPMIN * (DEPTH - 1)>();
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (T + DEPTH < ntiles) dma(T + DEPTH, (T + DEPTH) % NSLOT);
+          if (XPREF && tap == 7 && half == NH - 1 && chunk + 1 < p.nchunk) load_x(chunk + 1);
+          const unsigned char* wb = Ws + (T % NSLOT) * WSLOT;
+  #pragma unroll
+          for (int s = 0; s < KSTEPS; ++s) {
+            bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+  #pragma unroll
+            for (int i = 0; i < MI; ++i) {
+              ah[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * (half * KSTEPS + s));
+              if (NTERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(xa + aoff[i] + 32 * (half * KSTEPS + s) + 128);
+            }
+  #pragma unroll
+            for (int j = 0; j < NI; ++j) {
+              bh[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s);
+              if (NTERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j] + 32 * s + WK * 2);
+            }
+  #pragma unroll
+            for (int i = 0; i < MI; ++i)
+  #pragma unroll
+              for (int j = 0; j < NI; ++j) {
+                if (NTERMS == 3) {
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+              }
+          }
+        }
+      }
+      if (chunk + 1 < p.nchunk) {
+        __syncthreads();                 // every wave is done reading this chunk's input tile
+        if (!XPREF) load_x(chunk + 1);   // big-accumulator configuration: no registers to hold the prefetch across the taps
+        store_x();                       // (made visible by the barrier at the top of the next tap)
+      }
     }
   }
-
+  HX_T(2);
   // ---- epilogue: lane = output channel column, 16 pixels per m-tile ---------------------------------------------
   {
     const bool has_res = p.res != nullptr;
@@ -298,6 +366,11 @@ void conv3x3_halo_kernel(HaloParams p) {
       }
     }
   }
+  HX_T(3);
+#ifdef HX_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HX_T(4);
+#endif
 }
 
 template <int WM, int WN, int MI, int NI, int WK, int NSLOT, int NTERMS>
@@ -343,6 +416,11 @@ extern "C" long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn, int
 // one 16-row workgroup per CU the launch is as long as ONE workgroup's serial load / taps / store sequence.
 static int halo_rows_per_wg(int B, int H, int W, int Cout, int bn, int nterms) {
   if (bn == 128) return 8;
+  static const int blocked = []() { const char* e = getenv("FF_HALO_BLOCKED"); return e ? atoi(e) : 1; }();   // tuning switch
+  if (nterms == 1 && bn == 64 && blocked) {
+    const long long tiles16 = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + bn - 1) / bn);
+    if (tiles16 < 512 || blocked == 2) return 16;        // blocked 16-row form (launch table below)
+  }
   static const int wide8 = []() { const char* e = getenv("FF_HALO_192_8ROW"); return e ? atoi(e) : 0; }();   // tuning switch: 8-row form for 192 outputs (measured 36.9 vs 35.8 us on CAB 60->180, 67.1 vs 65.7 on 180->180: off)
   if (nterms == 1 && (bn <= 64 || (bn == 192 && wide8))) {
     const long long tiles16 = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + bn - 1) / bn);
@@ -374,8 +452,16 @@ extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int 
   p.in = in; p.w = (const unsigned char*)w_img; p.bias = bias; p.mul = mul; p.res = res; p.out = out;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.ldi = ldi; p.Cout = Cout; p.ldo = ldo; p.ldr = ldr;
   p.nchunk = (Cin + 63) / 64; p.act = act; p.alpha = alpha; p.shuffle = shuffle; p.pool_part = pool_partials;
+#ifdef HX_TIMING
+  p.dbg = g_hx_dbg;
+#endif
   hipStream_t st = (hipStream_t)stream;
   static const int ring = []() { const char* e = getenv("FF_HALO_RING"); return e ? atoi(e) : 0; }();   // tuning switch: weight-ring slots
+  static const int blocked = []() { const char* e = getenv("FF_HALO_BLOCKED"); return e ? atoi(e) : 1; }();
+  if (nterms == 1 && bn == 64 && blocked) {
+    const long long tiles16 = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + bn - 1) / bn);
+    if (tiles16 < 512 || blocked == 2) return launch_halo<8, 1, 1, 2, 64, 9, 1>(p, st);    // nine resident tap tiles, three barriers per chunk
+  }
   if (nterms == 1 && bn <= 64 && halo_rows_per_wg(B, H, W, Cout, bn, nterms) == 8) {   // 8x16 pixels, 4 waves
     if (bn == 32) return launch_halo<4, 1, 1, 1, 64, 2, 1>(p, st);
     if (ring == 3) return launch_halo<4, 1, 1, 2, 64, 3, 1>(p, st);
