@@ -20,6 +20,7 @@ struct HaloParams {
   int B, H, W, Cin, ldi, Cout, ldo, ldr, nchunk, tiles_x, tiles_y, nblk, act, shuffle;
   float alpha;
   float* pool_part;   // optional [workgroups][Cout padded to nblk*BN]: per-workgroup channel sums of the stored values
+  int io_bf16;        // nterms == 1 only: bit 0 = input rows are bf16 (ldi in elements), bit 1 = output rows are bf16 (ldo in elements)
 #ifdef HX_TIMING
   unsigned long long* dbg;   // tools/hx_time.cpp: [block][wave][8] wall-clock stamps (debug build only)
 #endif
@@ -150,7 +151,13 @@ void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
       const bool ok = cok && goff[j] >= 0;
-      const f32x4 u = *reinterpret_cast<const f32x4*>(p.in + (ok ? goff[j] + c0 : 0));
+      f32x4 u;
+      if (p.io_bf16 & 1) {                   // bf16 rows: four values are 8 bytes; the conversion back in store_x is exact
+        const bf16x4 h4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.in) + (ok ? goff[j] + c0 : 0));
+        u = (f32x4){(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+      } else {
+        u = *reinterpret_cast<const f32x4*>(p.in + (ok ? goff[j] + c0 : 0));
+      }
       xr[j] = ok ? u : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -331,7 +338,8 @@ void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float v = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
-              p.out[oidx[r]] = v;
+              if (p.io_bf16 & 2) reinterpret_cast<__bf16*>(p.out)[oidx[r]] = (__bf16)v;
+              else p.out[oidx[r]] = v;
               psum += v;
             }
           }
@@ -340,7 +348,8 @@ void conv3x3_halo_kernel(HaloParams p) {
           for (int r = 0; r < 16; ++r)
             if (okp[r]) {
               const float v = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
-              p.out[oidx[r]] = v;
+              if (p.io_bf16 & 2) reinterpret_cast<__bf16*>(p.out)[oidx[r]] = (__bf16)v;
+              else p.out[oidx[r]] = v;
               psum += v;
             }
         }
@@ -437,13 +446,14 @@ extern "C" long long ff_conv3x3_halo_pool_rows(int B, int H, int W, int Cout, in
 
 extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const float* bias, const float* mul,
                                const float* res, int ldr, float* out, int ldo, int B, int H, int W, int Cin, int Cout,
-                               int act, float alpha, int shuffle, float* pool_partials, int nterms, void* stream) {
+                               int act, float alpha, int shuffle, float* pool_partials, int nterms, int io_bf16, void* stream) {
   FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_conv3x3_halo: nterms must be 1 or 3");
+  FF_CHECK_ARG(io_bf16 == 0 || (nterms == 1 && io_bf16 > 0 && io_bf16 < 4 && shuffle == 0 && !res), "ff_conv3x3_halo: bf16 input / output rows exist for nterms == 1, no shuffle, no residual");
   FF_CHECK_ARG(in && w_img && out, "ff_conv3x3_halo: null pointer");
   FF_CHECK_ARG(!pool_partials || (shuffle == 0 && Cout <= bn), "ff_conv3x3_halo: pool partials need Cout <= bn and no pixel shuffle");
   FF_CHECK_ARG(shuffle == 0 || (shuffle == 2 && Cout % 4 == 0), "ff_conv3x3_halo: shuffle must be 0 or 2 (Cout %% 4 == 0)");
   FF_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "ff_conv3x3_halo: bad dims");
-  FF_CHECK_ARG(Cin % 4 == 0 && ldi % 4 == 0 && ldi >= Cin && (((uintptr_t)in) & 15) == 0, "ff_conv3x3_halo: input rows must be 16-byte aligned, Cin %% 4 == 0");
+  FF_CHECK_ARG(Cin % 4 == 0 && ldi % 4 == 0 && ldi >= Cin && (((uintptr_t)in) & 15) == 0, "ff_conv3x3_halo: input rows must be 16-byte aligned (8-byte for bf16 rows), Cin %% 4 == 0");
   FF_CHECK_ARG((((uintptr_t)w_img) & 15) == 0, "ff_conv3x3_halo: weight image must be 16-byte aligned");
   FF_CHECK_ARG(ldo >= (shuffle ? Cout / 4 : Cout) && (!res || ldr >= (shuffle ? Cout / 4 : Cout)), "ff_conv3x3_halo: ldo / ldr too small");
   FF_CHECK_ARG((long long)B * H * W * ldi < (1LL << 31), "ff_conv3x3_halo: input too large for 32-bit offsets");
@@ -451,7 +461,7 @@ extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int 
   HaloParams p;
   p.in = in; p.w = (const unsigned char*)w_img; p.bias = bias; p.mul = mul; p.res = res; p.out = out;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.ldi = ldi; p.Cout = Cout; p.ldo = ldo; p.ldr = ldr;
-  p.nchunk = (Cin + 63) / 64; p.act = act; p.alpha = alpha; p.shuffle = shuffle; p.pool_part = pool_partials;
+  p.nchunk = (Cin + 63) / 64; p.act = act; p.alpha = alpha; p.shuffle = shuffle; p.pool_part = pool_partials; p.io_bf16 = io_bf16;
 #ifdef HX_TIMING
   p.dbg = g_hx_dbg;
 #endif

@@ -35,7 +35,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct OcabParams {
   const float* qkv; float* out; const float* rel;
-  int ldq, ldo, q_off, k_off, v_off, o_off, B, H, W, nwx, nwy, heads;
+  int ldq, ldo, q_off, k_off, v_off, o_off, B, H, W, nwx, nwy, heads, out_bf16;
   float scale;
 };
 
@@ -220,7 +220,16 @@ __global__ __launch_bounds__(512) void ocab_attn_kernel(OcabParams p) {
       float lo, den;
       oc_halves(o[14], lo, den);
       const float inv = 1.0f / den;
-      if (qvalid) {
+      if (qvalid && p.out_bf16) {                       // bf16 rows (ldo in elements): the consumer rounds to bf16 anyway
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        __bf16* orow = reinterpret_cast<__bf16*>(p.out) + qtok * p.ldo + p.o_off + h * 30 + 4 * hh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = 8 * i + 4 * hh;
+          if (c < 30) *reinterpret_cast<bf16x2*>(orow + 8 * i) = (bf16x2){(__bf16)(o[4 * i] * inv), (__bf16)(o[4 * i + 1] * inv)};
+          if (c + 2 < 30) *reinterpret_cast<bf16x2*>(orow + 8 * i + 2) = (bf16x2){(__bf16)(o[4 * i + 2] * inv), (__bf16)(o[4 * i + 3] * inv)};
+        }
+      } else if (qvalid) {
         float* orow = p.out + qtok * p.ldo + p.o_off + h * 30 + 4 * hh;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(512) void ocab_attn_kernel(OcabParams p) {
 }
 
 extern "C" int ff_ocab_attn(const float* qkv, int ldq, int q_off, int k_off, int v_off, float* out, int ldo, int o_off,
-                            const float* rel_rotated, int B, int H, int W, int heads, int d, int ws, int ows, float scale, void* stream) {
+                            const float* rel_rotated, int B, int H, int W, int heads, int d, int ws, int ows, float scale, int out_bf16, void* stream) {
   FF_CHECK_ARG(qkv && out && rel_rotated, "ff_ocab_attn: null pointer");
   FF_CHECK_ARG(ws == 16 && ows == 24 && d == 30 && heads > 0, "ff_ocab_attn: built for 16x16 query / 24x24 key windows and head dim 30 (got %d / %d / %d)", ws, ows, d);
   FF_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, "ff_ocab_attn: H and W must be multiples of the window");
@@ -249,7 +258,7 @@ extern "C" int ff_ocab_attn(const float* qkv, int ldq, int q_off, int k_off, int
   FF_CHECK_ARG((long long)B * H * W * (ldq > ldo ? ldq : ldo) < (1LL << 31), "ff_ocab_attn: tensor too large for 32-bit token offsets");
   OcabParams p;
   p.qkv = qkv; p.out = out; p.rel = rel_rotated; p.ldq = ldq; p.ldo = ldo; p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.o_off = o_off;
-  p.B = B; p.H = H; p.W = W; p.nwx = W / 16; p.nwy = H / 16; p.heads = heads; p.scale = scale;
+  p.B = B; p.H = H; p.W = W; p.nwx = W / 16; p.nwy = H / 16; p.heads = heads; p.scale = scale; p.out_bf16 = out_bf16;
   const long long nblk = (long long)B * p.nwx * p.nwy;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_ocab_attn: grid too large");
   static_assert(OC_LDS <= 160 * 1024, "LDS image too large");

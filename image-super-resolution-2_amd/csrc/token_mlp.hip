@@ -336,6 +336,7 @@ struct TokenProjMlpParams {
   long long M;
   int lda, ldx, ldc, ldo, K, N, HT;
   float eps;
+  int io_bf16;            // plain-bf16 kernel only: bit 0 = att rows are bf16 (lda in elements), bit 1 = c2 rows are bf16 (ldc in elements)
 #ifdef TM_TIMING
   unsigned long long* dbg;   // tools/pm_time.cpp: [block][wave][64] wall-clock stamps (debug build only)
 #endif
@@ -729,7 +730,20 @@ __global__ __launch_bounds__(512) void token_projmlp_bf16_kernel(TokenProjMlpPar
 
   // ---- att rows -> bf16 fragments -------------------------------------------------------------------------------------------
   bf16x8 xh[TM_KS];
-  {
+  if (p.io_bf16 & 1) {
+    // bf16 att rows (written by the attention kernels' bf16 stores): a lane's fragment of k-step st IS 16 bytes of its token's row
+    const long long tk = tok0 + l31 < p.M ? tok0 + l31 : 0;
+    const __bf16* arow = reinterpret_cast<const __bf16*>(p.att) + tk * p.lda + 8 * hh;
+#pragma unroll
+    for (int st = 0; st < TM_KS; ++st) {
+      xh[st] = *reinterpret_cast<const bf16x8*>(arow + 16 * st);
+      if (16 * st + 8 * hh + 7 >= p.K) {               // the row's padding is never written: mask it
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (16 * st + 8 * hh + j >= p.K) xh[st][j] = (__bf16)0.f;
+      }
+    }
+  } else {
     float v[TM_KS][8];
     ff_wave_rows_to_frags<3>(p.att, p.lda, tok0, p.M, p.K, patch, lane, v);
 #pragma unroll
@@ -757,7 +771,11 @@ __global__ __launch_bounds__(512) void token_projmlp_bf16_kernel(TokenProjMlpPar
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       rx[i] = *reinterpret_cast<const f32x4*>(p.x + (xo[i] + cn));
-      if (p.c2) rc[i] = *reinterpret_cast<const f32x4*>(p.c2 + (co[i] + cn));
+      if (p.c2 && (p.io_bf16 & 2)) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const bf16x4 h4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.c2) + (co[i] + cn));
+        rc[i] = (f32x4){(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+      } else if (p.c2) rc[i] = *reinterpret_cast<const f32x4*>(p.c2 + (co[i] + cn));
     }
   };
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -943,8 +961,10 @@ __global__ __launch_bounds__(512) void token_projmlp_bf16_kernel(TokenProjMlpPar
 extern "C" int ff_token_projmlp(const float* att, int lda, const float* x, int ldx, const float* c2, int ldc, const float* c2_scale,
                                 float* out, int ldo, long long M, int K, int hidden_tiles, const void* proj_tiles,
                                 const float* proj_bias_padded, const float* gamma, const float* beta, float eps,
-                                const void* mlp_tiles, const float* b1_padded, const float* b2, int nterms, void* stream) {
+                                const void* mlp_tiles, const float* b1_padded, const float* b2, int nterms, int io_bf16, void* stream) {
   FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_token_projmlp: nterms must be 1 or 3");
+  FF_CHECK_ARG(io_bf16 == 0 || (nterms == 1 && io_bf16 > 0 && io_bf16 < 4), "ff_token_projmlp: bf16 att / c2 rows exist for nterms == 1 only");
+  FF_CHECK_ARG(!(io_bf16 & 1) || (lda % 8 == 0 && lda >= ((K + 15) / 16) * 16), "ff_token_projmlp: bf16 att rows must be 16-byte aligned and padded to a multiple of 16 channels");
   FF_CHECK_ARG(att && x && out && proj_tiles && proj_bias_padded && gamma && beta && mlp_tiles && b1_padded && b2, "ff_token_projmlp: null pointer");
   FF_CHECK_ARG(M > 0 && K > 0 && K <= TM_KP && K % 4 == 0 && hidden_tiles > 0, "ff_token_projmlp: needs K <= 192 (K %% 4 == 0)");
   FF_CHECK_ARG(lda >= K && lda % 4 == 0 && ldx >= K && ldx % 4 == 0 && ldo >= K && ldo % 4 == 0, "ff_token_projmlp: rows must be 16-byte aligned");
@@ -956,7 +976,7 @@ extern "C" int ff_token_projmlp(const float* att, int lda, const float* x, int l
   TokenProjMlpParams p;
   p.att = att; p.x = x; p.c2 = c2; p.rs2 = c2_scale; p.out = out; p.gamma = gamma; p.beta = beta;
   p.wp = (const __bf16*)proj_tiles; p.bp = proj_bias_padded; p.w = (const __bf16*)mlp_tiles; p.b1 = b1_padded; p.b2 = b2;
-  p.M = M; p.lda = lda; p.ldx = ldx; p.ldc = ldc; p.ldo = ldo; p.K = K; p.N = K; p.HT = hidden_tiles; p.eps = eps;
+  p.M = M; p.lda = lda; p.ldx = ldx; p.ldc = ldc; p.ldo = ldo; p.K = K; p.N = K; p.HT = hidden_tiles; p.eps = eps; p.io_bf16 = io_bf16;
 #ifdef TM_TIMING
   p.dbg = g_tm_dbg;
 #endif
@@ -974,6 +994,7 @@ extern "C" int ff_token_projmlp(const float* att, int lda, const float* x, int l
   }
   static int v2 = -1;
   if (v2 < 0) { const char* e = getenv("FF_PM_V2"); v2 = (e && e[0] == '0') ? 0 : 1; }
+  FF_CHECK_ARG(io_bf16 == 0 || v2, "ff_token_projmlp: bf16 att / c2 rows need the bf16 kernel (FF_PM_V2)");
   if (nterms == 1 && v2) {
     const size_t lds2 = (size_t)PM_OFF_VEC + (size_t)(2 * TM_KP + hidden_tiles * 32) * 4;
     FF_CHECK_ARG(lds2 <= 160 * 1024, "ff_token_projmlp: hidden too large for the LDS image");

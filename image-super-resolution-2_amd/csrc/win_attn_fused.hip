@@ -31,6 +31,7 @@ struct WinFusedParams {
   int ldx, ldo, ldxn, ldv, o_off, v_off;
   int B, H, W, Hp, Wp, sh, sw, use_mask, nwx, nwy;
   int head0, nheads, d, K, zero_pad, rel_rows, rel_stride, prio;
+  int out_bf16, xn_bf16;   // plain-bf16 kernel only: out / xn are bf16 rows (ldo / ldxn in elements) -- their consumers round to bf16 anyway
   float eps;
 #ifdef WF_TIMING
   unsigned long long* dbg;   // tools/wf_time.cpp: [block][wave][64] wall-clock stamps (debug build only)
@@ -480,9 +481,10 @@ extern "C" int ff_win_attn_fused(const float* x, int ldx, float* out, int ldo, i
                                  float eps, const void* w_tiles, const float* bias_padded, const float* rel_padded, int rel_rows,
                                  int rel_stride, int B, int H, int W, int Hp, int Wp, int wh, int ww, int shift_h, int shift_w,
                                  int use_mask, int head0, int nheads, int d, int K, int zero_pad_tokens, float* xn_out, int ldxn,
-                                 float* v_out, int ldv, int v_off, int nterms, void* stream) {
+                                 float* v_out, int ldv, int v_off, int nterms, int out_bf16, int xn_bf16, void* stream) {
   FF_CHECK_ARG(x && out && w_tiles && rel_padded, "ff_win_attn_fused: null pointer");
   FF_CHECK_ARG(nterms == 1 || nterms == 3, "ff_win_attn_fused: nterms must be 1 or 3");
+  FF_CHECK_ARG((!out_bf16 && !xn_bf16) || nterms == 1, "ff_win_attn_fused: bf16 outputs exist for nterms == 1 only");
   FF_CHECK_ARG(wh * ww == 256 && (ww == 8 || ww == 16 || ww == 32), "ff_win_attn_fused: window must hold 256 tokens, width 8 / 16 / 32 (got %dx%d)", wh, ww);
   FF_CHECK_ARG(K > 0 && K <= 192 && K % 4 == 0 && ldx >= K && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0, "ff_win_attn_fused: x rows must be <= 192 wide and 16-byte aligned");
   FF_CHECK_ARG(d > 0 && d <= 32 && d % 2 == 0 && nheads > 0 && nheads <= 6 && head0 >= 0, "ff_win_attn_fused: head dim %d / heads %d unsupported", d, nheads);
@@ -501,7 +503,7 @@ extern "C" int ff_win_attn_fused(const float* x, int ldx, float* out, int ldo, i
   p.xn = xn_out; p.vout = v_out; p.ldx = ldx; p.ldo = ldo; p.ldxn = ldxn; p.ldv = ldv; p.o_off = o_off; p.v_off = v_off;
   p.B = B; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.sh = shift_h; p.sw = shift_w; p.use_mask = use_mask;
   p.nwx = Wp / ww; p.nwy = Hp / wh; p.head0 = head0; p.nheads = nheads; p.d = d; p.K = K; p.zero_pad = zero_pad_tokens;
-  p.rel_rows = rel_rows; p.rel_stride = rel_stride; p.eps = eps;
+  p.rel_rows = rel_rows; p.rel_stride = rel_stride; p.eps = eps; p.out_bf16 = out_bf16; p.xn_bf16 = xn_bf16;
 #ifdef WF_TIMING
   p.dbg = g_wf_dbg;
 #endif
@@ -539,6 +541,8 @@ extern "C" int ff_win_attn_fused(const float* x, int ldx, float* out, int ldo, i
     hipLaunchKernelGGL((win_attn_fused_v2_kernel<WWV, ON>), dim3((unsigned)nblk), dim3(512), W2_LDS, (hipStream_t)stream, p); \
   } while (0)
 #define W2_LAUNCH(WWV) do { if (d == 30) W2_LAUNCH1(WWV, true); else W2_LAUNCH1(WWV, false); } while (0)
+  FF_CHECK_ARG((!out_bf16 && !xn_bf16) || v2, "ff_win_attn_fused: bf16 outputs need the v2 kernel (FF_WF_V2)");
+  FF_CHECK_ARG(!xn_bf16 || (ldxn % 8 == 0), "ff_win_attn_fused: bf16 xn rows must be 16-byte aligned");
   if (nterms == 1 && v2) {
     FF_CHECK_ARG((((uintptr_t)rel_padded) & 15) == 0, "ff_win_attn_fused: the bias table must be 16-byte aligned");
     if (ww == 8) W2_LAUNCH(8); else if (ww == 16) W2_LAUNCH(16); else W2_LAUNCH(32);

@@ -51,6 +51,8 @@ def _tl(blk: dict, key: str) -> dict:
     return pk
 
 
+# plain bf16: intermediates that are consumed only as bf16 MFMA operands live in HBM as bf16 (needs the v2 attention / proj + MLP kernels)
+_BF16_ROWS = (os.environ.get("FF_BF16_ROWS", "1") != "0" and os.environ.get("FF_WF_V2", "1") != "0" and os.environ.get("FF_PM_V2", "1") != "0")
 _OCAB_V2 = os.environ.get("FF_OCAB_V2", "1") != "0"          # plain bf16: HAT's overlapping cross-attention in the persistent per-window kernel
 _SGFN_TAIL = os.environ.get("FF_SGFN_TAIL", "1") != "0"      # plain bf16: DAT's SpatialGate + fc2 + residual in one launch
 _CAB_FUSED = os.environ.get("FF_CAB_FUSED", "0") == "1"        # opt-in: HAT's conv branch in one launch (csrc/cab_fused.hip); bit-identical to the two launches, measured no faster
@@ -180,13 +182,17 @@ class HatHIP:
     def hab(self, x: T, blk: dict) -> T:
         _, H, W, C = x.shape
         d = C // self.heads
-        att = ops.empty_like_rows(x)
+        # plain bf16: att, the normalised rows and conv1's output are consumed only as MFMA operands (rounded to bf16 there), so they are
+        # stored as bf16 -- bit-identical results, half the bytes; conv2's output enters x1 times conv_scale = 0.01 and goes the same way
+        b16 = (_BF16_ROWS and ops.gemm_mode() == "bf16" and _fast() and _WIN_FUSED and _PROJ_MLP and not _CAB_FUSED and x.shape[0] == 1
+               and H * W >= 1024 and C % 4 == 0)
+        att = ops.empty_rows_bf16(tuple(x.shape), x.device) if b16 else ops.empty_like_rows(x)
         s = blk["shift"]
         if _fast() and _WIN_FUSED:                                 # norm1 + qkv + (S)W-MSA of all six heads in one launch
             if "relp" not in blk:
                 blk["relp"] = pack_win_rel(blk["rel"], self.ws, self.ws)
             _, xn = ops.win_attn_fused(x, att, _wf(blk, self.heads, d), blk["relp"], gamma=blk["n1"][0], beta=blk["n1"][1], H=H, W=W,
-                                       Hp=H, Wp=W, win=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, want_xn=True)
+                                       Hp=H, Wp=W, win=(self.ws, self.ws), shift=(s, s), use_mask=s > 0, want_xn="bf16" if b16 else True)
         else:
             if _fast():                                            # LayerNorm inside the qkv launch; xn (conv branch) is its side output
                 qkv, xn = ops.token_linear(x, _tl(blk, "qkv"), gamma=blk["n1"][0], beta=blk["n1"][1], want_xn=True)
@@ -199,8 +205,8 @@ class HatHIP:
         if _CAB_FUSED and ops.gemm_mode() == "bf16" and blk["cab0"][0].shape[0] <= 64 and C <= 192 and x.shape[0] == 1:
             c2, c2mean = ops.cab_fused(xn, blk["cab0"][0], blk["cab0"][1], blk["cab2"][0], blk["cab2"][1], partials=True)   # conv -> GELU -> conv + pool, one launch
         else:
-            c1 = ops.conv2d(xn, *blk["cab0"], ksize=(3, 3), pad=(1, 1), act="gelu")
-            c2, c2mean = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1), want_pool="partials")   # pool partials from the conv epilogue
+            c1 = ops.conv2d(xn, *blk["cab0"], ksize=(3, 3), pad=(1, 1), act="gelu", out_bf16=b16)
+            c2, c2mean = ops.conv2d(c1, *blk["cab2"], ksize=(3, 3), pad=(1, 1), want_pool="partials", out_bf16=b16)   # pool partials from the conv epilogue
         gate = ops.vec_mlp(c2mean, *blk["ca1"], "relu", *blk["ca2"], "sigmoid", post=self.conv_scale)
         if _fast() and _PROJ_MLP:                                  # proj + both residuals + norm2 + MLP: x1 never reaches memory
             return ops.token_projmlp(att, x, _pm(blk), blk["n2"][0], blk["n2"][1], c2=c2, c2_scale=gate.reshape(-1))
@@ -218,8 +224,9 @@ class HatHIP:
             qkv = ops.token_linear(x, _tl(blk, "qkv"), gamma=blk["n1"][0], beta=blk["n1"][1])      # LayerNorm fused
         else:
             qkv = ops.linear(ops.layernorm(x, *blk["n1"]), *blk["qkv"])
-        att = ops.empty_like_rows(x)
-        if _OCAB_V2 and ops.gemm_mode() == "bf16" and (self.ws, self.ows, d) == (16, 24, 30) and H % 16 == 0 and W % 16 == 0:
+        ocab_v2 = _OCAB_V2 and ops.gemm_mode() == "bf16" and (self.ws, self.ows, d) == (16, 24, 30) and H % 16 == 0 and W % 16 == 0
+        att = ops.empty_rows_bf16(tuple(x.shape), x.device) if (ocab_v2 and _BF16_ROWS and _fast() and _PROJ_MLP) else ops.empty_like_rows(x)
+        if ocab_v2:
             ops.ocab_attn(qkv, att, blk["rel"], q_off=0, k_off=C, v_off=2 * C, H=H, W=W, heads=self.heads, d=d, ws=self.ws, ows=self.ows,
                           scale=d ** -0.5)                 # persistent per-window kernel, compact bias table in LDS (csrc/ocab_attn.hip)
         else:

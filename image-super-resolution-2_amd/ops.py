@@ -28,7 +28,8 @@ def _note(flops: float = 0.0, nbytes: float = 0.0):
 
 
 def _numel(*ts) -> float:
-    return float(sum(t.numel() for t in ts if t is not None))
+    """fp32-equivalent element count (a bf16 tensor counts half: _note multiplies by 4 bytes)."""
+    return float(sum(t.numel() * (t.element_size() / 4.0) for t in ts if t is not None))
 
 
 def _instrument(fn):
@@ -117,6 +118,13 @@ _PAD_PITCH = _os.environ.get("FF_PAD_PITCH", "1") != "0"
 
 
 _PAD_ROWS = _os.environ.get("FF_PAD_ROWS", "1") != "0"
+
+
+def empty_rows_bf16(shape, device) -> T:
+    """bf16 activation buffer [..., C] for an intermediate whose only consumer rounds it to bf16 anyway (plain-bf16 mode); the row
+    pitch is a multiple of 64 elements (128 bytes)."""
+    C = int(shape[-1])
+    return torch.empty(tuple(shape[:-1]) + ((C + 63) // 64 * 64,), device=device, dtype=torch.bfloat16)[..., :C]
 
 
 def empty_rows(shape, device) -> T:
@@ -288,8 +296,8 @@ def _stream() -> int:
 
 
 def _chk(t: T, name: str):
-    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32:
-        raise _lib.FFError(f"{name}: expected a CUDA(HIP) float32 tensor")
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or (t.dtype != torch.float32 and not (t.dtype == torch.bfloat16 and name.endswith("|bf16ok"))):
+        raise _lib.FFError(f"{name.split('|')[0]}: expected a CUDA(HIP) float32 tensor")
 
 
 def _ptr(t: Optional[T]) -> Optional[int]:
@@ -341,12 +349,13 @@ class PoolPartials:
 
 def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1), pad=(0, 0), act=None,
            res: Optional[T] = None, mul: Optional[T] = None, alpha: float = 1.0, shuffle: int = 0,
-           out: Optional[T] = None, tile_hint: int = 0, dynamic_w: bool = False, want_pool: bool = False):
+           out: Optional[T] = None, tile_hint: int = 0, dynamic_w: bool = False, want_pool: bool = False, out_bf16: bool = False):
     """x [B,H,W,Cin] (rows view), w packed [Cout, KH*KW*Cin] -> [B,Ho,Wo,Cout] (or pixel-shuffled).
     want_pool (B == 1): also return the global average pool [1, Cout] of the output -> (out, pooled); the LDS-resident 3x3
     kernel produces it from its epilogue, any other path falls back to ff_pool_mean on the output.  want_pool="partials":
     the second value is a PoolPartials when the epilogue produced partial sums (else the finished pool)."""
-    xp, ldi, B, H, W, Cin = _nhwc(x, "conv2d.x")
+    in_bf16 = x.dtype == torch.bfloat16
+    xp, ldi, B, H, W, Cin = _nhwc(x, "conv2d.x|bf16ok" if in_bf16 else "conv2d.x")
     KH, KW = ksize
     Cout = w.shape[0]
     if w.dim() != 2 or w.shape[1] != KH * KW * Cin or not w.is_contiguous():
@@ -355,10 +364,16 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
     Wo = (W + 2 * pad[1] - KW) // stride[1] + 1
     oshape = (B, Ho * 2, Wo * 2, Cout // 4) if shuffle == 2 else (B, Ho, Wo, Cout)
     if out is None:
-        out = empty_rows(oshape, x.device)
+        out = empty_rows_bf16(oshape, x.device) if out_bf16 else empty_rows(oshape, x.device)
     elif tuple(out.shape) != oshape:
         raise _lib.FFError(f"conv2d: out shape {tuple(out.shape)} != {oshape}")
-    op, ldo, *_ = _nhwc(out, "conv2d.out")
+    out_bf16 = out.dtype == torch.bfloat16
+    op, ldo, *_ = _nhwc(out, "conv2d.out|bf16ok" if out_bf16 else "conv2d.out")
+    halo_ok = (_HALO and _GEMM_MODE in ("bf16x3", "bf16") and (KH, KW) == (3, 3) and tuple(stride) == (1, 1) and tuple(pad) == (1, 1)
+               and not dynamic_w and Cin >= 32 and Cin % 4 == 0 and ldi % 4 == 0 and xp % 16 == 0
+               and (Cout <= 64 or Cin >= 128 or 128 < Cout <= 192 or _HALO_ALL) and H * W >= 1024 and xp != op and B * H * W * ldi < 2 ** 31)
+    if (in_bf16 or out_bf16) and not (halo_ok and _GEMM_MODE == "bf16" and shuffle == 0 and res is None):
+        raise _lib.FFError("conv2d: bf16 input / output rows exist for the LDS-resident 3x3 kernel in plain-bf16 mode only")
     rp, ldr = None, 0
     if res is not None:
         if tuple(res.shape) != oshape:
@@ -394,7 +409,8 @@ def conv2d(x: T, w: T, bias: Optional[T] = None, *, ksize=(1, 1), stride=(1, 1),
             prow = int(_L().ff_conv3x3_halo_pool_rows(B, H, W, Cout, img[1], nt_))
             part = torch.empty((prow, img[1]), device=x.device, dtype=torch.float32)
         _lib.check(_L().ff_conv3x3_halo(xp, ldi, img[0].data_ptr(), img[1], _ptr(bias), _ptr(mul), rp, ldr, op, ldo, B, H, W,
-                                        Cin, Cout, ACT[act], float(alpha), shuffle, _ptr(part), _nterms(), _stream()))
+                                        Cin, Cout, ACT[act], float(alpha), shuffle, _ptr(part), _nterms(),
+                                        (1 if in_bf16 else 0) | (2 if out_bf16 else 0), _stream()))
         if part is not None:
             pp = PoolPartials(part, Cout, 1.0 / float(H * W))
             _note(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, 4.0 * (_numel(x, w, out, res)))
@@ -519,11 +535,12 @@ def ocab_attn(qkv: T, out: T, rel_rotated: T, *, q_off: int, k_off: int, v_off: 
     if _GEMM_MODE != "bf16":
         raise _lib.FFError("ocab_attn exists for the plain-bf16 contraction mode only")
     qp, ldq, B, h_, w_, _ = _nhwc(qkv, "ocab_attn.qkv")
-    op, ldo, *_ = _nhwc(out, "ocab_attn.out")
+    out_bf16 = out.dtype == torch.bfloat16
+    op, ldo, *_ = _nhwc(out, "ocab_attn.out|bf16ok" if out_bf16 else "ocab_attn.out")
     if (h_, w_) != (H, W) or tuple(out.shape[:3]) != (B, H, W) or tuple(rel_rotated.shape) != (heads, (ws + ows - 1) ** 2) or not rel_rotated.is_contiguous():
         raise _lib.FFError("ocab_attn: shape mismatch")
     _lib.check(_L().ff_ocab_attn(qp, ldq, q_off, k_off, v_off, op, ldo, o_off, rel_rotated.data_ptr(), B, H, W, heads, d, ws, ows,
-                                 float(scale), _stream()))
+                                 float(scale), int(out_bf16), _stream()))
     nwin = B * (H // ws) * (W // ws)
     _note(4.0 * nwin * heads * ws * ws * ows * ows * d, 4.0 * B * H * W * heads * d * 4)
     return out
@@ -537,7 +554,11 @@ def win_attn_fused(x: T, out: T, pk: dict, rel_padded: T, *, gamma: Optional[T],
     prep.pack_win_attn, rel_padded from prep.pack_win_rel.  x [B,H,W,K] rows view; out [B,H,W,>= o_off + heads*d].
     want_xn: also return the normalised rows; v_out: receives v of the processed heads at channel v_off + g*d."""
     xp, ldx, B, h_, w_, K = _nhwc(x, "win_attn_fused.x")
-    op, ldo, *_ = _nhwc(out, "win_attn_fused.out")
+    out_bf16 = out.dtype == torch.bfloat16
+    op, ldo, *_ = _nhwc(out, "win_attn_fused.out|bf16ok" if out_bf16 else "win_attn_fused.out")
+    xn_bf16 = want_xn == "bf16"
+    if (out_bf16 or xn_bf16) and _GEMM_MODE != "bf16":
+        raise _lib.FFError("win_attn_fused: bf16 outputs exist for the plain-bf16 contraction mode only")
     if (h_, w_) != (H, W) or tuple(out.shape[:3]) != (B, H, W) or K != pk["K"]:
         raise _lib.FFError("win_attn_fused: x/out dims mismatch")
     nheads = pk["heads"] - head0 if nheads is None else nheads
@@ -547,8 +568,8 @@ def win_attn_fused(x: T, out: T, pk: dict, rel_padded: T, *, gamma: Optional[T],
         raise _lib.FFError("win_attn_fused exists for the bf16 contraction modes only")
     xn, xnp, ldxn = None, None, 0
     if want_xn:
-        xn = empty_like_rows(x)
-        xnp, ldxn, _, _ = rows_view(xn, "win_attn_fused.xn")
+        xn = empty_rows_bf16(tuple(x.shape), x.device) if xn_bf16 else empty_like_rows(x)
+        xnp, ldxn, _, _ = rows_view(xn, "win_attn_fused.xn|bf16ok" if xn_bf16 else "win_attn_fused.xn")
     vp, ldv = None, 0
     if v_out is not None:
         vp, ldv, vb, vh, vw, _ = _nhwc(v_out, "win_attn_fused.v_out")
@@ -557,10 +578,11 @@ def win_attn_fused(x: T, out: T, pk: dict, rel_padded: T, *, gamma: Optional[T],
     _lib.check(_L().ff_win_attn_fused(xp, ldx, op, ldo, o_off, _ptr(gamma), _ptr(beta), float(eps), pk["w"].data_ptr(),
                                       pk["b"].data_ptr(), rel_padded.data_ptr(), rel_padded.shape[1], rel_padded.shape[2], B, H, W,
                                       Hp, Wp, win[0], win[1], shift[0], shift[1], int(use_mask), head0, nheads, pk["d"], K,
-                                      int(zero_pad), xnp, ldxn, vp, ldv, v_off, 1 if _GEMM_MODE == "bf16" else 3, _stream()))
+                                      int(zero_pad), xnp, ldxn, vp, ldv, v_off, 1 if _GEMM_MODE == "bf16" else 3, int(out_bf16), int(xn_bf16),
+                                      _stream()))
     nwin = B * (Hp // win[0]) * (Wp // win[1])
     _note(2.0 * nwin * 256 * K * 3 * nheads * pk["d"] + 4.0 * nwin * nheads * 256 * 256 * pk["d"],
-          4.0 * B * H * W * (K * (2 if want_xn else 1) + nheads * pk["d"] * (2 if v_out is not None else 1)))
+          4.0 * B * H * W * (K * (1 + (0 if not want_xn else (0.5 if xn_bf16 else 1.0))) + nheads * pk["d"] * ((0.5 if out_bf16 else 1.0) + (1 if v_out is not None else 0))))
     return (out, xn) if want_xn else out
 
 
@@ -581,13 +603,17 @@ def token_projmlp(att: T, x: T, pk: dict, gamma: T, beta: T, *, c2: Optional[T] 
                   eps: float = 1e-5) -> T:
     """x1 = x + proj(att) + c2 * c2_scale; return x1 + fc2(GELU(fc1(LayerNorm(x1)))) in one launch (bf16x3); pk from
     prep.pack_token_projmlp."""
-    ap, lda, rows, K = rows_view(att, "token_projmlp.att")
+    att_bf16 = att.dtype == torch.bfloat16
+    c2_bf16 = c2 is not None and c2.dtype == torch.bfloat16
+    if (att_bf16 or c2_bf16) and _GEMM_MODE != "bf16":
+        raise _lib.FFError("token_projmlp: bf16 att / c2 rows exist for the plain-bf16 contraction mode only")
+    ap, lda, rows, K = rows_view(att, "token_projmlp.att|bf16ok" if att_bf16 else "token_projmlp.att")
     xp, ldx, xr, xk = rows_view(x, "token_projmlp.x")
     if xr != rows or xk != K or K != pk["mlp"]["K"]:
         raise _lib.FFError("token_projmlp: shape mismatch")
     cp, ldc = None, 0
     if c2 is not None:
-        cp, ldc, cr, ck = rows_view(c2, "token_projmlp.c2")
+        cp, ldc, cr, ck = rows_view(c2, "token_projmlp.c2|bf16ok" if c2_bf16 else "token_projmlp.c2")
         if cr != rows or ck != K or c2_scale is None or c2_scale.numel() != K:
             raise _lib.FFError("token_projmlp: c2 shape mismatch")
     out = empty_like_rows(x)
@@ -595,8 +621,8 @@ def token_projmlp(att: T, x: T, pk: dict, gamma: T, beta: T, *, c2: Optional[T] 
     m = pk["mlp"]
     _lib.check(_L().ff_token_projmlp(ap, lda, xp, ldx, cp, ldc, _ptr(c2_scale), op_, ldo_, rows, K, m["ht"], pk["proj"]["w"].data_ptr(),
                                      pk["proj"]["b"].data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), m["w"].data_ptr(),
-                                     m["b1"].data_ptr(), m["b2"].data_ptr(), _nterms(), _stream()))
-    _note(2.0 * rows * K * K + 4.0 * rows * K * m["ht"] * 32, 4.0 * rows * K * (3 + (c2 is not None)))
+                                     m["b1"].data_ptr(), m["b2"].data_ptr(), _nterms(), (1 if att_bf16 else 0) | (2 if c2_bf16 else 0), _stream()))
+    _note(2.0 * rows * K * K + 4.0 * rows * K * m["ht"] * 32, 4.0 * rows * K * (2 + (0.5 if att_bf16 else 1.0) + (0 if c2 is None else (0.5 if c2_bf16 else 1.0))))
     return out
 
 

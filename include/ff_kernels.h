@@ -100,11 +100,14 @@ int ff_window_attn_bf16s(const float* qkv, int ldq, int q_off, int k_off, int v_
  * mlp_tiles: ff_token_mlp's format with fc1's K columns in the accumulator-operand order (prep.pack_token_projmlp);
  * c2 / c2_scale may be NULL (no convolution branch).  K = N <= 192.
  * nterms (here and in every token / halo / NAFNet kernel below): 3 = split-bf16 products hi*lo + lo*hi + hi*hi (fp32-grade results),
- * 1 = plain bf16 operands (hi*hi only: a third of the MFMAs; the weight images are the same, their lo planes unused). */
+ * 1 = plain bf16 operands (hi*hi only: a third of the MFMAs; the weight images are the same, their lo planes unused).
+ * io_bf16 (nterms == 1 only; the pointers are then bf16 rows with the pitch in elements): bit 0 = att, bit 1 = c2.  An intermediate
+ * whose only consumer rounds it to bf16 as an MFMA operand can be stored as bf16 with bit-identical results (att, the normalised rows
+ * of ff_win_attn_fused, conv1's output inside CAB); c2 enters x1 times conv_scale = 0.01, where the rounding is 2e-5 of x1. */
 int ff_token_projmlp(const float* att, int lda, const float* x, int ldx, const float* c2, int ldc, const float* c2_scale,
                      float* out, int ldo, long long M, int K, int hidden_tiles, const void* proj_tiles,
                      const float* proj_bias_padded, const float* gamma, const float* beta, float eps,
-                     const void* mlp_tiles, const float* b1_padded, const float* b2, int nterms, void* stream);
+                     const void* mlp_tiles, const float* b1_padded, const float* b2, int nterms, int io_bf16, void* stream);
 
 /* Window-resident attention block (csrc/win_attn_fused.hip): LayerNorm -> q/k/v projection -> softmax(q k^T + bias (+mask)) v
  * for ALL `nheads` heads of one 256-token window per workgroup; the qkv tensor never exists in memory.
@@ -122,12 +125,13 @@ int ff_token_projmlp(const float* att, int lda, const float* x, int ldx, const f
  *   0: such tokens do not occur (HAT pads the image beforehand).
  *   xn_out (optional): the LayerNorm'ed rows [tokens][ldxn] (HAT's conv branch input, hat_arch.py:274).
  *   v_out (optional): v of the processed heads, v_out[token][v_off + g*d ..) (DAT's depth-wise conv branch, dat_arch.py:524).
- * nterms 3 = split-bf16 (fp32-grade), 1 = plain bf16. */
+ * nterms 3 = split-bf16 (fp32-grade), 1 = plain bf16.  out_bf16 / xn_bf16 (nterms == 1 only): out / xn_out are bf16 rows, pitches in
+ * elements (xn rows padded to a multiple of 8). */
 int ff_win_attn_fused(const float* x, int ldx, float* out, int ldo, int o_off, const float* gamma, const float* beta,
                       float eps, const void* w_tiles, const float* bias_padded, const float* rel_padded, int rel_rows,
                       int rel_stride, int B, int H, int W, int Hp, int Wp, int wh, int ww, int shift_h, int shift_w,
                       int use_mask, int head0, int nheads, int d, int K, int zero_pad_tokens, float* xn_out, int ldxn,
-                      float* v_out, int ldv, int v_off, int nterms, void* stream);
+                      float* v_out, int ldv, int v_off, int nterms, int out_bf16, int xn_bf16, void* stream);
 
 /* Fused transformer feed-forward on tokens (csrc/token_mlp.hip): out = x + fc2(GELU(fc1(LayerNorm(x)))), bf16x3 MFMA.
  * Replaces hat_arch.py:307 (norm2 + Mlp.forward :88-94 + residual) in one launch; the hidden activation stays on chip.
@@ -149,12 +153,14 @@ int ff_token_mlp(const float* x, int ldx, float* out, int ldo, long long M, int 
  * workgroups per CU), of ff_conv3x3_halo_weight_bytes(Cout, Cin, bn, nterms) bytes (-1: bad arguments).  Needs Cin % 4 == 0, 16-byte aligned rows. */
 long long ff_conv3x3_halo_weight_bytes(int Cout, int Cin, int bn, int nterms);
 /* pool_partials (optional, Cout <= bn, no shuffle): [ff_conv3x3_halo_pool_rows(B,H,W,Cout,bn,nterms)][bn] per-workgroup channel sums of the
- * stored output, finished by ff_pool_finish (the global average pool of hat_arch.py:50 without re-reading the tensor). */
+ * stored output, finished by ff_pool_finish (the global average pool of hat_arch.py:50 without re-reading the tensor).
+ * io_bf16 (nterms == 1, no shuffle, no residual): bit 0 = `in` rows are bf16, bit 1 = `out` rows are bf16 (pitches in elements; the
+ * pool partials are taken from the fp32 values before rounding). */
 long long ff_conv3x3_halo_pool_rows(int B, int H, int W, int Cout, int bn, int nterms);
 int ff_pool_finish(const float* part, int rows, int ld, int C, float inv_count, float* out, void* stream);
 int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int bn, const float* bias, const float* mul,
                     const float* res, int ldr, float* out, int ldo, int B, int H, int W, int Cin, int Cout,
-                    int act, float alpha, int shuffle, float* pool_partials, int nterms, void* stream);
+                    int act, float alpha, int shuffle, float* pool_partials, int nterms, int io_bf16, void* stream);
 
 /* HAT's convolution branch in one launch, plain bf16 (csrc/cab_fused.hip; hat_arch.py:61-74 CAB = conv3x3 Cin -> Cmid, GELU,
  * conv3x3 Cmid -> Cout, and the per-workgroup channel sums of the result for ChannelAttention's global average pool, :50):
@@ -248,7 +254,7 @@ int ff_pool_vec_mlp(const float* part, int rows, int ld, float inv_count, int Ci
  * relative_position_bias_table rotated as prep.pack_rel_overlap does (the reference gathers it with negative, wrapped indices).
  * One persistent workgroup per window; built for ws = 16, ows = 24, d = 30 (anything else: ff_window_attn_bf16s). */
 int ff_ocab_attn(const float* qkv, int ldq, int q_off, int k_off, int v_off, float* out, int ldo, int o_off,
-                 const float* rel_rotated, int B, int H, int W, int heads, int d, int ws, int ows, float scale, void* stream);
+                 const float* rel_rotated, int B, int H, int W, int heads, int d, int ws, int ows, float scale, int out_bf16, void* stream);
 
 /* DAT SGFN tail in one launch (plain bf16 MFMA, fp32 accumulate; dat_arch.py:117-123, 163-170, 736):
  *   out = res + W2 . ( h[:, :c2] * (dw3x3(LayerNorm(h[:, c2:2 c2])) + dw_bias) ) + b2

@@ -17,7 +17,7 @@ def test_library_builds_and_exports_header_symbols():
     for name in protos:
         assert hasattr(handle, name), f"{name} declared in include/ff_kernels.h but not exported"
     lib = L.load()
-    assert lib.ff_abi_version() == 5
+    assert lib.ff_abi_version() == 6
     assert lib.ff_last_error() is not None
 
 

@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
   hipMalloc(&part, prow * bn * 4);
   const size_t ndbg = 4096 * 8 * 8; hipMalloc(&dbg, ndbg * 8);
   hipMemcpy(x, hx.data(), M * Cin * 4, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), wb, hipMemcpyHostToDevice); hipMemset(bias, 0, 1024);
-  auto run = [&]() { return ff_conv3x3_halo(x, Cin, w, bn, bias, nullptr, nullptr, 0, out, Cout, 1, H, W, Cin, Cout, Cout <= 64 ? 1 : 0, 1.f, 0, (pool && Cout <= bn) ? part : nullptr, nterms, nullptr); };
+  auto run = [&]() { return ff_conv3x3_halo(x, Cin, w, bn, bias, nullptr, nullptr, 0, out, Cout, 1, H, W, Cin, Cout, Cout <= 64 ? 1 : 0, 1.f, 0, (pool && Cout <= bn) ? part : nullptr, nterms, 0, nullptr); };
   g_hx_dbg = nullptr;
   for (int i = 0; i < 3; ++i) if (run()) { printf("error: %s\n", g_err); return 1; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

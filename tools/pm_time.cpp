@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
   hipMemcpy(dwp, wp.data(), wp.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dwm, wm.data(), wm.size() * 2, hipMemcpyHostToDevice);
   auto run = [&]() {
     return ff_token_projmlp(att, C, x, C, with_c2 ? c2 : nullptr, C, with_c2 ? vec : nullptr, out, C, M, C, HT, dwp, vec + 256, vec + 512, vec + 768, 1e-5f,
-                            dwm, vec + 1024, vec + 2048, nterms, nullptr);
+                            dwm, vec + 1024, vec + 2048, nterms, 0, nullptr);
   };
   g_tm_dbg = nullptr;
   for (int i = 0; i < 3; ++i) if (run()) { printf("error: %s\n", g_err); return 1; }

@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
   hipMemcpy(be, hbe.data(), 192 * 4, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
   auto run = [&]() {
     return ff_win_attn_fused(x, C, out, C, 0, g, be, 1e-5f, w, b, rel, 31, 48, 1, H, W, H, W, ws, ws, shift, shift, shift > 0, 0, heads, d, C, 0,
-                             want_xn ? xn : nullptr, C, nullptr, 0, 0, nterms, nullptr);
+                             want_xn ? xn : nullptr, C, nullptr, 0, 0, nterms, 0, 0, nullptr);
   };
   g_wf_dbg = nullptr;
   for (int i = 0; i < 3; ++i) if (run()) { printf("error: %s\n", g_err); return 1; }
