@@ -20,6 +20,7 @@ struct HaloParams {
   int B, H, W, Cin, ldi, Cout, ldo, ldr, nchunk, tiles_x, tiles_y, nblk, act, shuffle;
   float alpha;
   float* pool_part;   // optional [workgroups][Cout padded to nblk*BN]: per-workgroup channel sums of the stored values
+  int vec_epi;        // 16-byte epilogue through LDS patches (set by the launcher when the layout allows)
   int io_bf16;        // nterms == 1 only: bit 0 = input rows are bf16 (ldi in elements), bit 1 = output rows are bf16 (ldo in elements)
 #ifdef HX_TIMING
   unsigned long long* dbg;   // tools/hx_time.cpp: [block][wave][8] wall-clock stamps (debug build only)
@@ -300,6 +301,77 @@ void conv3x3_halo_kernel(HaloParams p) {
     }
   }
   HX_T(2);
+  // ---- vector epilogue (no pixel shuffle, Cout % 4 == 0, 16-byte aligned rows): every 32 x 32 accumulator tile goes through the wave's
+  //      LDS patch so that a lane owns four consecutive channels of a pixel -- four 16-byte stores of whole 128-byte pixel segments per
+  //      tile instead of sixteen 4-byte stores (tools/hx_time.cpp: the scalar epilogue was 10.7 us of CAB 60->180's 32 us and did not
+  //      shrink when the output went to bf16: it is bound by store instructions, not by bytes) ------------------------------------------
+  if (p.vec_epi) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // every wave has left the tap loop: the staging area is free
+    float* ps = reinterpret_cast<float*>(smem);          // [WM][BN] pool partials (first 8 KB), then the waves' 32 x 36 patches
+    float* patch = reinterpret_cast<float*>(smem + 8192) + wid * (32 * 36);
+    const int tq = lane >> 3, q4 = 4 * (lane & 7);
+    const bool has_res = p.res != nullptr;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wc * TN + j * 32 + l31;
+      const bool nok = n < p.Cout;
+      const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+      const float mv = ((nok && p.mul) ? p.mul[n] : 1.f) * p.alpha;
+      const int c4 = n0 + wc * TN + j * 32 + q4;         // the four channels this lane stores
+      const bool cok = c4 < p.Cout;
+      f32x4 mv4 = {p.alpha, p.alpha, p.alpha, p.alpha};
+      if (p.mul && cok) mv4 = *reinterpret_cast<const f32x4*>(p.mul + c4) * p.alpha;
+      float psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int ry0 = y0 + (wr * MI + i) * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                   // register r = tile row (r & 3) + 8 (r >> 2) + 4 hh of channel l31
+          const int mrow = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const float a = ff_act_c<ACT, true>(acc[i][j][r] + bv);
+          patch[mrow * 36 + l31] = a;                      // scale and residual are applied after the transposition, as one fma (the scalar path's rounding)
+          if (nok && ry0 + (mrow >> 4) < p.H && x0 + (mrow & 15) < p.W) psum += a * mv;  // (pool partials: no residual on this path)
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int mrow = tq + 8 * k;
+          const int oy = ry0 + (mrow >> 4), ox = x0 + (mrow & 15);
+          const bool ok = cok && oy < p.H && ox < p.W;
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(patch + mrow * 36 + q4);
+          const long long pix = ok ? ((long long)(b * p.H + oy) * p.W + ox) : 0;
+          f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+          if (has_res && ok) r4 = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + c4);
+          f32x4 v4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v4[e] = __builtin_fmaf(a4[e], mv4[e], r4[e]);
+          if (ok) {
+            if (p.io_bf16 & 2) {
+              bf16x4 h4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) h4[e] = (__bf16)v4[e];
+              *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + pix * p.ldo + c4) = h4;
+            } else {
+              *reinterpret_cast<f32x4*>(p.out + pix * p.ldo + c4) = v4;
+            }
+          }
+        }
+      }
+      if (p.pool_part) {
+        psum += __shfl_xor(psum, 32);
+        if (hh == 0) ps[wr * BN + wc * TN + j * 32 + l31] = psum;
+      }
+    }
+    if (p.pool_part) {
+      __syncthreads();
+      for (int c = threadIdx.x; c < BN; c += NT) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) sacc += ps[w * BN + c];
+        p.pool_part[(long long)blockIdx.x * BN + c] = sacc;
+      }
+    }
+  } else
   // ---- epilogue: lane = output channel column, 16 pixels per m-tile ---------------------------------------------
   {
     const bool has_res = p.res != nullptr;
@@ -337,7 +409,7 @@ void conv3x3_halo_kernel(HaloParams p) {
           if (nok) {                         // one exec mask for the whole tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
+              const float v = __builtin_fmaf(ff_act_c<ACT, true>(acc[i][j][r] + bv), mv, rv[r]);
               if (p.io_bf16 & 2) reinterpret_cast<__bf16*>(p.out)[oidx[r]] = (__bf16)v;
               else p.out[oidx[r]] = v;
               psum += v;
@@ -347,7 +419,7 @@ void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (okp[r]) {
-              const float v = ff_act_c<ACT, true>(acc[i][j][r] + bv) * mv + rv[r];
+              const float v = __builtin_fmaf(ff_act_c<ACT, true>(acc[i][j][r] + bv), mv, rv[r]);
               if (p.io_bf16 & 2) reinterpret_cast<__bf16*>(p.out)[oidx[r]] = (__bf16)v;
               else p.out[oidx[r]] = v;
               psum += v;
@@ -388,6 +460,7 @@ static int launch_halo(HaloParams& p, hipStream_t st) {
   constexpr int WSLOT = ((BN * ((NTERMS == 1 ? WK * 2 : WK * 4) + 16) + 1023) / 1024) * 1024;
   constexpr size_t lds = (size_t)(TH + 2) * HaloGeom<NTERMS>::PROW + NSLOT * WSLOT;
   static_assert(lds <= 160 * 1024, "LDS budget");
+  static_assert(lds >= 8192 + (size_t)WM * WN * 32 * 36 * 4, "the vector epilogue's pool row + patches must fit in the staging area");
   p.tiles_x = (p.W + 15) / 16;
   p.tiles_y = (p.H + TH - 1) / TH;
   p.nblk = (p.Cout + BN - 1) / BN;
@@ -462,6 +535,9 @@ extern "C" int ff_conv3x3_halo(const float* in, int ldi, const void* w_img, int 
   p.in = in; p.w = (const unsigned char*)w_img; p.bias = bias; p.mul = mul; p.res = res; p.out = out;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.ldi = ldi; p.Cout = Cout; p.ldo = ldo; p.ldr = ldr;
   p.nchunk = (Cin + 63) / 64; p.act = act; p.alpha = alpha; p.shuffle = shuffle; p.pool_part = pool_partials; p.io_bf16 = io_bf16;
+  static const int vec_epi_on = []() { const char* e = getenv("FF_HALO_VEC_EPI"); return e ? atoi(e) : 1; }();   // tuning switch
+  p.vec_epi = vec_epi_on && shuffle == 0 && Cout % 4 == 0 && ldo % 4 == 0 && (((uintptr_t)out) & 15) == 0 && !(res && pool_partials) &&
+              (!res || (ldr % 4 == 0 && (((uintptr_t)res) & 15) == 0)) && (!mul || (((uintptr_t)mul) & 15) == 0);
 #ifdef HX_TIMING
   p.dbg = g_hx_dbg;
 #endif
