@@ -63,20 +63,29 @@ __global__ __launch_bounds__(384) void chan_gram_kernel(const float* __restrict_
   }
 }
 
-// stage 2: many workgroups sum the per-block partials (coalesced over the 5760 statistics)
+// stage 2: 180 workgroups of 32 statistics x 8 block slices: a thread sums every 8th partial block of its statistic (four independent
+// accumulators: 8 dependent load rounds at nblk = 256 instead of 64), the slices meet in LDS in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ part, int nblk, float* __restrict__ G) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= 5760) return;
+  __shared__ float red[8][32];
+  const int l = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + l;                       // 5760 = 180 x 32
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblk; b += 4) {
+  int b = sl;
+  for (; b + 24 < nblk; b += 32) {
     s0 += part[(long long)b * 5760 + e];
-    s1 += part[(long long)(b + 1) * 5760 + e];
-    s2 += part[(long long)(b + 2) * 5760 + e];
-    s3 += part[(long long)(b + 3) * 5760 + e];
+    s1 += part[(long long)(b + 8) * 5760 + e];
+    s2 += part[(long long)(b + 16) * 5760 + e];
+    s3 += part[(long long)(b + 24) * 5760 + e];
   }
-  for (; b < nblk; ++b) s0 += part[(long long)b * 5760 + e];
-  G[e] = (s0 + s1) + (s2 + s3);
+  for (; b < nblk; b += 8) s0 += part[(long long)b * 5760 + e];
+  red[sl][l] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][l];
+    G[e] = t;
+  }
 }
 
 // stage 3: normalise, softmax rows, emit block-diagonal weight Wbd[co][ci] (one thread per (row, column))
@@ -113,7 +122,7 @@ extern "C" int ff_chan_attn_weights(const float* qkv, int ld, int q_off, int k_o
   hipStream_t st = (hipStream_t)stream;
   float* G = work + (long long)nblk * 5760;
   hipLaunchKernelGGL(chan_gram_kernel, dim3(nblk), dim3(384), 0, st, qkv, ld, q_off, k_off, N, tpb, work);
-  hipLaunchKernelGGL(chan_reduce_kernel, dim3((5760 + 255) / 256), dim3(256), 0, st, work, nblk, G);
+  hipLaunchKernelGGL(chan_reduce_kernel, dim3(5760 / 32), dim3(256), 0, st, work, nblk, G);
   hipLaunchKernelGGL(chan_attn_weights_kernel, dim3(180), dim3(64), 0, st, G, temperature, wbd);
   FF_LAUNCH_CHECK("ff_chan_attn_weights");
   return FF_OK;
@@ -125,7 +134,7 @@ extern "C" int ff_chan_attn_finish(float* work, long long work_floats, int nblk,
   FF_CHECK_ARG(work_floats >= (long long)(nblk + 1) * 5760, "ff_chan_attn_finish: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* G = work + (long long)nblk * 5760;
-  hipLaunchKernelGGL(chan_reduce_kernel, dim3((5760 + 255) / 256), dim3(256), 0, st, work, nblk, G);
+  hipLaunchKernelGGL(chan_reduce_kernel, dim3(5760 / 32), dim3(256), 0, st, work, nblk, G);
   hipLaunchKernelGGL(chan_attn_weights_kernel, dim3(180), dim3(64), 0, st, G, temperature, wbd);
   FF_LAUNCH_CHECK("ff_chan_attn_finish");
   return FF_OK;
