@@ -153,7 +153,7 @@ void conv3x3_halo_kernel(HaloParams p) {
     for (int j = 0; j < NPASS; ++j) {
       const bool ok = cok && goff[j] >= 0;
       f32x4 u;
-      if (p.io_bf16 & 1) {                   // bf16 rows: four values are 8 bytes; the conversion back in store_x is exact
+      if (NTERMS == 1 && (p.io_bf16 & 1)) {                   // bf16 rows: four values are 8 bytes; the conversion back in store_x is exact
         const bf16x4 h4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.in) + (ok ? goff[j] + c0 : 0));
         u = (f32x4){(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
       } else {
@@ -312,6 +312,22 @@ void conv3x3_halo_kernel(HaloParams p) {
     float* patch = reinterpret_cast<float*>(smem + 8192) + wid * (32 * 36);
     const int tq = lane >> 3, q4 = 4 * (lane & 7);
     const bool has_res = p.res != nullptr;
+    // residual quads are requested one n-tile ahead of their use (fetched right before the add, each tile exposed an HBM latency: the
+    // finding of sgfn_tail's epilogue; all tiles at once spills the big-accumulator forms)
+    constexpr bool RES_AHEAD = !(TWO_PER_CU || (NTERMS == 1 && MI * NI <= 2 && WM * WN == 4));   // the 128- / 168-register forms fetch at use
+    f32x4 rq[2][MI][4];
+    auto load_res = [&](int j, f32x4 (&dst)[MI][4]) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int mrow = tq + 8 * k, c4 = n0 + wc * TN + j * 32 + q4;
+          const int oy = y0 + (wr * MI + i) * 2 + (mrow >> 4), ox = x0 + (mrow & 15);
+          const bool ok = c4 < p.Cout && oy < p.H && ox < p.W;
+          dst[i][k] = ok ? *reinterpret_cast<const f32x4*>(p.res + ((long long)(b * p.H + oy) * p.W + ox) * p.ldr + c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (RES_AHEAD && has_res) load_res(0, rq[0]);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int n = n0 + wc * TN + j * 32 + l31;
@@ -320,6 +336,7 @@ void conv3x3_halo_kernel(HaloParams p) {
       const float mv = ((nok && p.mul) ? p.mul[n] : 1.f) * p.alpha;
       const int c4 = n0 + wc * TN + j * 32 + q4;         // the four channels this lane stores
       const bool cok = c4 < p.Cout;
+      if (RES_AHEAD && has_res && j + 1 < NI) load_res(j + 1, rq[(j + 1) & 1]);
       f32x4 mv4 = {p.alpha, p.alpha, p.alpha, p.alpha};
       if (p.mul && cok) mv4 = *reinterpret_cast<const f32x4*>(p.mul + c4) * p.alpha;
       float psum = 0.f;
@@ -341,12 +358,13 @@ void conv3x3_halo_kernel(HaloParams p) {
           const f32x4 a4 = *reinterpret_cast<const f32x4*>(patch + mrow * 36 + q4);
           const long long pix = ok ? ((long long)(b * p.H + oy) * p.W + ox) : 0;
           f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
-          if (has_res && ok) r4 = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + c4);
+          if (RES_AHEAD && has_res) r4 = rq[j & 1][i][k];
+          else if (has_res && ok) r4 = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + c4);
           f32x4 v4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v4[e] = __builtin_fmaf(a4[e], mv4[e], r4[e]);
           if (ok) {
-            if (p.io_bf16 & 2) {
+            if (NTERMS == 1 && (p.io_bf16 & 2)) {
               bf16x4 h4;
 #pragma unroll
               for (int e = 0; e < 4; ++e) h4[e] = (__bf16)v4[e];
@@ -410,7 +428,7 @@ void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float v = __builtin_fmaf(ff_act_c<ACT, true>(acc[i][j][r] + bv), mv, rv[r]);
-              if (p.io_bf16 & 2) reinterpret_cast<__bf16*>(p.out)[oidx[r]] = (__bf16)v;
+              if (NTERMS == 1 && (p.io_bf16 & 2)) reinterpret_cast<__bf16*>(p.out)[oidx[r]] = (__bf16)v;
               else p.out[oidx[r]] = v;
               psum += v;
             }
@@ -420,7 +438,7 @@ void conv3x3_halo_kernel(HaloParams p) {
           for (int r = 0; r < 16; ++r)
             if (okp[r]) {
               const float v = __builtin_fmaf(ff_act_c<ACT, true>(acc[i][j][r] + bv), mv, rv[r]);
-              if (p.io_bf16 & 2) reinterpret_cast<__bf16*>(p.out)[oidx[r]] = (__bf16)v;
+              if (NTERMS == 1 && (p.io_bf16 & 2)) reinterpret_cast<__bf16*>(p.out)[oidx[r]] = (__bf16)v;
               else p.out[oidx[r]] = v;
               psum += v;
             }

@@ -40,7 +40,16 @@ struct SgfnParams {
   const float* h; const float* stats; const float* gamma; const float* beta; const float* dww; const float* dwb;
   const __bf16* w2; const float* b2; const float* res; float* out;
   int ldh, c2, ldr, ldo, B, H, W, N, HT, ntx, nty;
+#ifdef SG_TIMING
+  unsigned long long* dbg;   // tools/sg_time.cpp: [block][wave][8] wall-clock stamps (debug build only)
+#endif
 };
+#ifdef SG_TIMING
+static unsigned long long* g_sg_dbg = nullptr;
+#define SG_T(i) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define SG_T(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(512) void sgfn_tail_kernel(SgfnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -54,6 +63,7 @@ __global__ __launch_bounds__(512) void sgfn_tail_kernel(SgfnParams p) {
   const int ty = bid % p.nty;
   const int b = bid / p.nty;
   const int y0 = ty * SG_TH, x0 = tx * SG_TW;
+  SG_T(0);
 
   // ---- per-workgroup tables: halo pixel -> token (or -1), its LayerNorm statistics; gamma / beta ------------------------------
   if (tid < SG_HP) {
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(512) void sgfn_tail_kernel(SgfnParams p) {
     }
   };
 
+  SG_T(1);
   stage_load(0);
   x1_load(0, x1c);
   stage_store(0, 0);
@@ -149,6 +160,7 @@ __global__ __launch_bounds__(512) void sgfn_tail_kernel(SgfnParams p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  SG_T(2);
   for (int c = 0; c < p.HT; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < p.HT;
@@ -192,12 +204,24 @@ __global__ __launch_bounds__(512) void sgfn_tail_kernel(SgfnParams p) {
     __builtin_amdgcn_s_barrier();                        // chunk c+1 is staged and its fc2 tile has landed; every wave is done with chunk c
   }
 
+  SG_T(3);
   // ---- epilogue: + b2 + residual, through the wave's LDS patch (the halo buffers are idle) into 128-byte row segments ---------
   {
     float* patch = reinterpret_cast<float*>(smem) + wid * (32 * 36);
     const int tq = lane >> 3, q4 = 4 * (lane & 7);
     const bool rowok = cy < p.H;
     const long long tok0 = (long long)(b * p.H + (rowok ? cy : 0)) * p.W + x0;
+    // every residual quad of the wave's 32 x 192 output is requested up front (tools/sg_time.cpp: fetched tile by tile after the
+    // transposition each one exposed its HBM latency -- the epilogue was 26.5 us of the launch's 93)
+    f32x4 rq[6][4];
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t = tq + 8 * i, c4 = n * 32 + q4;
+        const bool ok = p.res && c4 < p.N && rowok && x0 + t < p.W;
+        rq[n][i] = ok ? *reinterpret_cast<const f32x4*>(p.res + (tok0 + t) * p.ldr + c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
     for (int n = 0; n < 6; ++n) {
       const int c4 = n * 32 + q4;
@@ -213,14 +237,16 @@ __global__ __launch_bounds__(512) void sgfn_tail_kernel(SgfnParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int t = tq + 8 * i;
-        f32x4 ov = *reinterpret_cast<const f32x4*>(patch + t * 36 + q4) + b4;
-        if (cok && rowok && x0 + t < p.W) {
-          if (p.res) ov += *reinterpret_cast<const f32x4*>(p.res + (tok0 + t) * p.ldr + c4);
-          *reinterpret_cast<f32x4*>(p.out + (tok0 + t) * p.ldo + c4) = ov;
-        }
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(patch + t * 36 + q4) + b4 + rq[n][i];
+        if (cok && rowok && x0 + t < p.W) *reinterpret_cast<f32x4*>(p.out + (tok0 + t) * p.ldo + c4) = ov;
       }
     }
   }
+  SG_T(4);
+#ifdef SG_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SG_T(5);
+#endif
 }
 
 extern "C" int ff_sgfn_tail(const float* h, int ldh, int c2, const float* stats, const float* gamma, const float* beta,
@@ -238,6 +264,9 @@ extern "C" int ff_sgfn_tail(const float* h, int ldh, int c2, const float* stats,
   p.h = h; p.stats = stats; p.gamma = gamma; p.beta = beta; p.dww = dw_tapmajor; p.dwb = dw_bias; p.w2 = (const __bf16*)fc2_tiles;
   p.b2 = b2; p.res = res; p.out = out; p.ldh = ldh; p.c2 = c2; p.ldr = ldr; p.ldo = ldo; p.B = B; p.H = H; p.W = W; p.N = N; p.HT = hidden_tiles;
   p.ntx = (W + SG_TW - 1) / SG_TW; p.nty = (H + SG_TH - 1) / SG_TH;
+#ifdef SG_TIMING
+  p.dbg = g_sg_dbg;
+#endif
   const long long nblk = (long long)B * p.ntx * p.nty;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_sgfn_tail: grid too large");
   static_assert(SG_LDS <= 160 * 1024, "LDS image too large");
