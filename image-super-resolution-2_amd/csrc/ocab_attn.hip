@@ -37,7 +37,16 @@ struct OcabParams {
   const float* qkv; float* out; const float* rel;
   int ldq, ldo, q_off, k_off, v_off, o_off, B, H, W, nwx, nwy, heads, out_bf16;
   float scale;
+#ifdef OC_TIMING
+  unsigned long long* dbg;   // tools/oc_time.cpp: [block][wave][64] wall-clock stamps (debug build only)
+#endif
 };
+#ifdef OC_TIMING
+static unsigned long long* g_oc_dbg = nullptr;
+#define OC_T(i) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 64 + (i)] = wall_clock64(); } while (0)
+#else
+#define OC_T(i) do { } while (0)
+#endif
 
 typedef __attribute__((address_space(3))) const float* oc_lds_cf;
 
@@ -59,6 +68,7 @@ __global__ __launch_bounds__(512) void ocab_attn_kernel(OcabParams p) {
   const int wx = bid % p.nwx; bid /= p.nwx;
   const int wy = bid % p.nwy;
   const int b = bid / p.nwy;
+  OC_T(0);
 
   // ---- key table in TILE order: key index 32 T + kappa, T = 3 tr + tc, is window position (4 tr + kappa / 8, 8 tc + kappa % 8) ---
   for (int kidx = tid; kidx < OC_NK; kidx += 512) {
@@ -93,12 +103,19 @@ __global__ __launch_bounds__(512) void ocab_attn_kernel(OcabParams p) {
   float2 stg[OC_NLOAD];
   float tb[3];
   float2 qn[8];
-  auto stage_load = [&](int h, int st) {
+  unsigned stg_ok = 0u;                                 // validity of the staged keys (bit i): applied when the stage is STORED -- a select
+                                                        // on the loaded value here would make every load wait for its data (measured: 3.5 us
+                                                        // per stage just to "issue" the loads, tools/oc_time.cpp)
+  // in two halves: a wave stalls at issue once it has more than a dozen or so loads outstanding (tools/oc_time.cpp: "issuing" all 18 took
+  // 3.6 us = the latency of the first ones); the second half is issued a third of the way into the stage's tiles
+  auto stage_load = [&](int h, int st, int part) {
+    if (part == 0) stg_ok = 0u;
 #pragma unroll
     for (int i = 0; i < OC_NLOAD; ++i) {
+      if ((i < OC_NLOAD / 2) != (part == 0)) continue;
       const int tk = s_on ? ktok[st * OC_STK + skey + 16 * i] : -1;
-      const float2 u = *reinterpret_cast<const float2*>(p.qkv + (tk >= 0 ? (long long)tk * p.ldq + s_ch + h * 30 : 0));
-      stg[i] = tk >= 0 ? u : (float2){0.f, 0.f};
+      stg_ok |= (tk >= 0 ? 1u : 0u) << i;
+      stg[i] = *reinterpret_cast<const float2*>(p.qkv + (tk >= 0 ? (long long)tk * p.ldq + s_ch + h * 30 : 0));
     }
   };
   auto stage_store = [&](int buf) {
@@ -108,7 +125,8 @@ __global__ __launch_bounds__(512) void ocab_attn_kernel(OcabParams p) {
 #pragma unroll
       for (int i = 0; i < OC_NLOAD; ++i) {
         const int kl = skey + 16 * i;
-        const __bf16 a = (__bf16)stg[i].x, c = (__bf16)stg[i].y;
+        const bool ok = (stg_ok >> i) & 1u;
+        const __bf16 a = (__bf16)(ok ? stg[i].x : 0.f), c = (__bf16)(ok ? stg[i].y : 0.f);
         if (s_isk) {
           const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, c) << 16);
           *reinterpret_cast<unsigned*>(kb + kl * OC_KROWB + 4 * spr) = pk;
@@ -147,13 +165,15 @@ __global__ __launch_bounds__(512) void ocab_attn_kernel(OcabParams p) {
       }
   };
 
-  stage_load(0, 0);
+  stage_load(0, 0, 0);
+  stage_load(0, 0, 1);
   head_load(0);
   stage_store(0);
   head_store(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  OC_T(1);
   f32x16 o;
   float m_run = -INFINITY;
   const int nsteps = 2 * p.heads;
@@ -161,9 +181,10 @@ __global__ __launch_bounds__(512) void ocab_attn_kernel(OcabParams p) {
     const int h = n >> 1, st = n & 1, buf = n & 1;
     const bool more = n + 1 < nsteps;
     if (more) {
-      stage_load((n + 1) >> 1, (n + 1) & 1);
+      stage_load((n + 1) >> 1, (n + 1) & 1, 0);
       if (st == 1) head_load(h + 1);
     }
+    if (n < 4) OC_T(2 + 4 * n);
     if (st == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -174,6 +195,7 @@ __global__ __launch_bounds__(512) void ocab_attn_kernel(OcabParams p) {
     const unsigned rel0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(smem + OC_OFF_REL + (h & 1) * OC_RELB) +
                           4u * (unsigned)(rel_lane + st * (12 * OC_RELW));
     for (int tq = 0; tq < 3; ++tq) {
+      if (more && tq == 1) stage_load((n + 1) >> 1, (n + 1) & 1, 1);
 #pragma unroll
       for (int tm = 0; tm < 3; ++tm) {
         const int t = 3 * tq + tm;
@@ -216,6 +238,7 @@ __global__ __launch_bounds__(512) void ocab_attn_kernel(OcabParams p) {
         }
       }
     }
+    if (n < 4) OC_T(3 + 4 * n);
     if (st == 1) {                                       // head finished: channel 30 = register 14 of the upper half-wave holds sum(P)
       float lo, den;
       oc_halves(o[14], lo, den);
@@ -243,9 +266,12 @@ __global__ __launch_bounds__(512) void ocab_attn_kernel(OcabParams p) {
       stage_store(buf ^ 1);
       if (st == 1) head_store(h + 1);
     }
+    if (n < 4) OC_T(4 + 4 * n);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                        // the next stage is in LDS; every wave is done with this one
+    if (n < 4) OC_T(5 + 4 * n);
   }
+  OC_T(60);
 }
 
 extern "C" int ff_ocab_attn(const float* qkv, int ldq, int q_off, int k_off, int v_off, float* out, int ldo, int o_off,
@@ -259,6 +285,9 @@ extern "C" int ff_ocab_attn(const float* qkv, int ldq, int q_off, int k_off, int
   OcabParams p;
   p.qkv = qkv; p.out = out; p.rel = rel_rotated; p.ldq = ldq; p.ldo = ldo; p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.o_off = o_off;
   p.B = B; p.H = H; p.W = W; p.nwx = W / 16; p.nwy = H / 16; p.heads = heads; p.scale = scale; p.out_bf16 = out_bf16;
+#ifdef OC_TIMING
+  p.dbg = g_oc_dbg;
+#endif
   const long long nblk = (long long)B * p.nwx * p.nwy;
   FF_CHECK_ARG(nblk < (1LL << 31), "ff_ocab_attn: grid too large");
   static_assert(OC_LDS <= 160 * 1024, "LDS image too large");
